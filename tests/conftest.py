@@ -1,0 +1,50 @@
+import json
+import os
+import struct
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def model_dir(tmp_path_factory):
+    return str(tmp_path_factory.mktemp("models"))
+
+
+@pytest.fixture(scope="session")
+def tok_golden():
+    with open(os.path.join(GOLDEN, "tokenizer_golden.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def write_vocab_only_model(path, vocab, n_max_tokens=512):
+    """Header + vocab of the bert.cpp file format and no tensors (enough for the tokenizer)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", 0x67676D6C))
+        f.write(struct.pack("<7i", len(vocab), n_max_tokens, 384, 1536, 12, 6, 1))
+        for tok in vocab:
+            b = tok if isinstance(tok, bytes) else tok.encode("utf-8")
+            f.write(struct.pack("<I", len(b)))
+            f.write(b)
+
+
+@pytest.fixture(scope="session")
+def sparse_vocab_model(tok_golden, model_dir):
+    n = tok_golden["n_vocab"]
+    vocab = [f"[unused{i}]" for i in range(n)]
+    vocab[0], vocab[100], vocab[101], vocab[102], vocab[103] = "[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"
+    for i, p in tok_golden["sparse_vocab"].items():
+        vocab[int(i)] = p
+    path = os.path.join(model_dir, "sparse_vocab.bin")
+    write_vocab_only_model(path, vocab)
+    return path
