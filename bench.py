@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py — sentences/sec of the bert_eval hot path on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (bert_hip_eval_packed_device: embeddings -> L encoder
+layers -> mean-pool + L2) over one batch of synthetic token ids that is already resident in HBM;
+with --gpus N > 1 each rank evaluates its own shard of sentences (weights replicated, no data-path
+collective inside the forward pass) and the step ends with ONE RCCL all-gather of the final
+embeddings over xGMI, as BASELINE.json's north_star describes.  value = sentences all ranks
+processed / max-over-ranks wall time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     — dominant kernel, algorithmic FLOPs per launch / HIP-event launch duration vs the
+                 dense f16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline — the CPU oracle in ggml-faithful mode (kind "port": the reference itself cannot be
+                 built, its arithmetic lives in the un-vendored ggml submodule) timed on this box's
+                 host cores over a bounded sample of the same sentences.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("BERT_HIP_QUIET", "1")
+
+from bert_cpp_amd import ggml_file as gf  # noqa: E402
+from bert_cpp_amd import pybert  # noqa: E402
+
+MFMA_PEAK_F16 = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md §Matrix cores
+
+# BASELINE.json configs[1..4]; configs[0] is the CPU-only plumbing case (= the cpu_baseline leg).
+CONFIGS = {
+    1: dict(name="all-MiniLM-L6-v2 f16, batch=256 seq_len=128", dims="minilm-l6", ftype="f16", batch=256, seq_len=128),
+    2: dict(name="all-MiniLM-L6-v2 q4_0, batch=1024 seq_len=128", dims="minilm-l6", ftype="q4_0", batch=1024, seq_len=128),
+    3: dict(name="bert-base-uncased q4_1, batch=512 seq_len=512", dims="bert-base", ftype="q4_1", batch=512, seq_len=512),
+    4: dict(name="mpnet-base dims (BERT arch) q4_0, seq_len=128, 8192-sentence steps", dims="mpnet-dims", ftype="q4_0",
+            batch=8192, seq_len=128),
+}
+
+
+def flops_per_sentence(hp, n):
+    H, I, L = hp.n_embd, hp.n_intermediate, hp.n_layer
+    return L * (n * (8 * H * H + 4 * H * I) + 4 * n * n * H) + 2 * n * H
+
+
+def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir):
+    cfg = CONFIGS[cfg_id]
+    hp = gf.MODEL_DIMS[cfg["dims"]]
+    path = os.path.join(tmpdir, f"{cfg['dims']}_{cfg['ftype']}_rank{rank}.bin")
+    if not os.path.exists(path):
+        gf.make_synthetic_model(path, cfg["dims"], cfg["ftype"], seed=0)
+    model = pybert.BertModel(path)
+    B, N, H = cfg["batch"], cfg["seq_len"], hp.n_embd
+    ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + cfg_id + 1000 * rank)
+    d_tokens = torch.from_numpy(ids.reshape(-1)).to(device)
+    d_cu = torch.arange(0, (B + 1) * N, N, dtype=torch.int32, device=device)
+    d_out = torch.empty((B, H), dtype=torch.float32, device=device)
+    d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, B * N, N, d_out.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI: the path's one exchange step
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    sent_per_s = world * B * args.steps / dt
+    res = dict(cfg=cfg, hp=hp, model=model, path=path, ids=ids, out=d_out, dt=dt, value=sent_per_s,
+               ms_per_step=1e3 * dt / args.steps, step=step)
+    return res
+
+
+def kernel_roofline(res, torch, device, steps=5):
+    """Per-kernel HIP-event timing in a separate pass (events around every launch, on the launch stream)."""
+    model = res["model"]
+    model.profile(True)
+    for _ in range(steps):
+        res["step"]()
+    torch.cuda.synchronize(device)
+    rep = model.profile_report()
+    model.profile(False)
+    if not rep:
+        return None, rep
+    name, st = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
+    avg_s = st["total_ms"] / st["launches"] * 1e-3
+    achieved = st["flops_per_launch"] / avg_s if avg_s > 0 else 0.0
+    total_ms = sum(v["total_ms"] for v in rep.values())
+    roof = {"bound": "mfma", "kernel": name, "achieved": achieved / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
+            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_F16, "traffic": None,
+            "avg_launch_us": avg_s * 1e6, "flops_per_launch": st["flops_per_launch"],
+            "kernel_time_share": st["total_ms"] / total_ms if total_ms else None}
+    breakdown = {k: round(v["total_ms"] / steps, 4) for k, v in sorted(rep.items())}
+    return roof, breakdown
+
+
+def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=32):
+    """Oracle (ggml-faithful mode) on the host cores over a bounded sample of the same sentences."""
+    from oracle import oracle as orc
+
+    o = orc.Oracle(res["path"])
+    cores = os.cpu_count() or 1
+    gpu = res["out"].cpu().numpy()
+    ids = res["ids"]
+    o.eval(ids[0], orc.MODE_GGML, cores)            # warm-up (tables, page-in)
+    n, t0, coss = 0, time.perf_counter(), []
+    while n < max_sent and n < len(ids) and (time.perf_counter() - t0 < budget_s or n < 2):
+        ref = o.eval(ids[n], orc.MODE_GGML, cores)
+        coss.append(float(gpu[n] @ ref / (np.linalg.norm(gpu[n]) * np.linalg.norm(ref))))
+        n += 1
+    dt = time.perf_counter() - t0
+    base = {"value": n / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the step's sentences (seq_len {ids.shape[1]}), oracle ggml-faithful mode, "
+                      f"OpenMP {cores} threads, {dt:.1f} s"}
+    return base, float(np.mean(coss)), float(np.min(coss)), n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--also", type=int, nargs="*", default=None,
+                    help="extra BASELINE configs reported under 'also' (default at N=1: config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    with tempfile.TemporaryDirectory(prefix="bert_bench_") as tmpdir:
+        res = run_config(args.config, args, rank, world, device, dist, torch, tmpdir)
+        line = None
+        if rank == 0:
+            cfg, hp = res["cfg"], res["hp"]
+            fps = flops_per_sentence(hp, cfg["seq_len"])
+            line = {
+                "metric": "sentences/sec (seq_len=%d)" % cfg["seq_len"], "value": res["value"], "unit": "sentences/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+                "data": "synthetic (seeded random weights in bert.cpp file format, random token ids)",
+                "config": {"workload": cfg["name"], "per_gpu_batch": cfg["batch"], "global_batch": cfg["batch"] * world,
+                           "seq_len": cfg["seq_len"], "weights": cfg["ftype"],
+                           "parallelism": f"dp{world} (replicated weights, sharded sentences"
+                                          + (", RCCL all-gather of embeddings per step)" if world > 1 else ")")},
+                "path_gflop_per_sentence": fps / 1e9,
+                "path_mfma_frac": res["value"] * fps / (world * MFMA_PEAK_F16),
+            }
+        roof, breakdown = kernel_roofline(res, torch, device)
+        if rank == 0:
+            line["roofline"] = roof
+            line["kernel_ms_per_step"] = breakdown
+            if world == 1 and not args.no_cpu_baseline:
+                base, mean_cos, min_cos, n = cpu_baseline_and_cosine(res)
+                line["cpu_baseline"] = base
+                line["mean_cosine_vs_cpu"] = mean_cos
+                line["min_cosine_vs_cpu"] = min_cos
+                line["speedup_vs_cpu"] = res["value"] / base["value"]
+        res["model"].close()
+        also = args.also if args.also is not None else ([2] if world == 1 and args.config == 1 else [])
+        extras = {}
+        for cid in also:
+            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir)
+            if rank == 0:
+                fps2 = flops_per_sentence(r2["hp"], r2["cfg"]["seq_len"])
+                e = {"workload": r2["cfg"]["name"], "value": r2["value"], "unit": "sentences/s",
+                     "ms_per_step": r2["ms_per_step"], "path_mfma_frac": r2["value"] * fps2 / (world * MFMA_PEAK_F16)}
+                roof2, bd2 = kernel_roofline(r2, torch, device, steps=3)
+                e["roofline"] = roof2
+                e["kernel_ms_per_step"] = bd2
+                if world == 1 and not args.no_cpu_baseline:
+                    base2, mc, mn, _ = cpu_baseline_and_cosine(r2, budget_s=8.0, max_sent=16)
+                    e.update(cpu_baseline=base2, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn,
+                             speedup_vs_cpu=r2["value"] / base2["value"])
+                extras[f"config{cid}"] = e
+            else:
+                kernel_roofline(r2, torch, device, steps=3)
+            r2["model"].close()
+        if rank == 0:
+            if extras:
+                line["also"] = extras
+            print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+// bert_api.cpp — the C ABI of libbert.so: bert.h (the reference's API, symbol for symbol) and the
+// bert_hip.h extensions.  Host-side glue only; every FLOP of bert_eval runs in the HIP kernels.
+//
+// Reference behaviour mirrored here (reference file:line):
+//   bert_load_from_file  bert.cpp:331-694    bert_free          bert.cpp:715-718
+//   bert_tokenize        bert.cpp:252-325    bert_eval          bert.cpp:720-728
+//   bert_eval_batch      bert.cpp:730-941    bert_encode        bert.cpp:943-950
+//   bert_encode_batch    bert.cpp:952-1022   accessors          bert.cpp:111-134
+//   bert_params_parse    bert.cpp:140-193
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/bert.h"
+#include "../../include/bert_hip.h"
+#include "engine.h"
+#include "model_file.h"
+#include "tokenizer.h"
+
+using namespace bert_hip;
+
+struct bert_ctx {
+    HParams hp;
+    Tokenizer tok;
+    std::unique_ptr<Engine> engine;   // null for tokenizer-only contexts
+};
+
+namespace {
+
+bool quiet_env() {
+    const char *q = getenv("BERT_HIP_QUIET");
+    return q && *q && *q != '0';
+}
+
+bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
+    const bool quiet = quiet_env();
+    if (!quiet) printf("%s: loading model from '%s' - please wait ...\n", "bert_load_from_file", fname);
+    ModelFile mf;
+    std::string err;
+    if (!mf.load(fname, tokenizer_only, err)) {
+        fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
+        return nullptr;
+    }
+    if (!quiet) {
+        printf("%s: n_vocab = %d\n%s: n_max_tokens   = %d\n%s: n_embd  = %d\n%s: n_intermediate  = %d\n"
+               "%s: n_head  = %d\n%s: n_layer = %d\n%s: f16     = %d\n",
+               "bert_load_from_file", mf.hp.n_vocab, "bert_load_from_file", mf.hp.n_max_tokens, "bert_load_from_file",
+               mf.hp.n_embd, "bert_load_from_file", mf.hp.n_intermediate, "bert_load_from_file", mf.hp.n_head,
+               "bert_load_from_file", mf.hp.n_layer, "bert_load_from_file", mf.hp.f16);
+    }
+    std::unique_ptr<bert_ctx> ctx(new bert_ctx);
+    ctx->hp = mf.hp;
+    ctx->tok.build(std::move(mf.vocab));
+    if (!tokenizer_only) {
+        Engine *e = Engine::create(mf, err);
+        if (!e) {
+            fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
+            return nullptr;
+        }
+        ctx->engine.reset(e);
+        if (!quiet)
+            printf("%s: model size = %8.2f MB / num tensors = %zu (HBM-resident on HIP device %d)\n", "bert_load_from_file",
+                   mf.total_tensor_bytes / 1024.0 / 1024.0, mf.tensors.size(), e->device());
+    }
+    return ctx.release();
+}
+
+// Validates sentence b; returns false (after the reference's stderr message) if it cannot be evaluated.
+bool sentence_ok(const bert_ctx *ctx, const bert_vocab_id *toks, int32_t n) {
+    if (n > ctx->hp.n_max_tokens) {
+        fprintf(stderr, "Too many tokens, maximum is %d\n", ctx->hp.n_max_tokens);   // reference bert.cpp:765-769
+        return false;
+    }
+    if (n <= 0 || !toks) {
+        fprintf(stderr, "bert_eval_batch: empty input\n");
+        return false;
+    }
+    for (int32_t i = 0; i < n; ++i)
+        if (toks[i] < 0 || toks[i] >= ctx->hp.n_vocab) {
+            fprintf(stderr, "bert_eval_batch: token id %d out of range [0, %d)\n", toks[i], ctx->hp.n_vocab);
+            return false;
+        }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------------------------------------
+// bert.h
+// ------------------------------------------------------------------------------------------------
+bool bert_params_parse(int argc, char **argv, bert_params &params) {
+    auto usage = [&]() {
+        fprintf(stderr, "usage: %s [options]\n\noptions:\n", argv[0]);
+        fprintf(stderr, "  -h, --help            show this help message and exit\n");
+        fprintf(stderr, "  -t N, --threads N     accepted for compatibility, ignored by the GPU engine (default: %d)\n", params.n_threads);
+        fprintf(stderr, "  -p PROMPT, --prompt PROMPT\n                        text to embed (default: %s)\n", params.prompt);
+        fprintf(stderr, "  --port p              port to bind in server mode (default: %d)\n", params.port);
+        fprintf(stderr, "  -m FNAME, --model FNAME\n                        model path (default: %s)\n\n", params.model);
+    };
+    for (int i = 1; i < argc; ++i) {
+        const std::string arg = argv[i];
+        const bool has_value = i + 1 < argc;
+        if ((arg == "-t" || arg == "--threads") && has_value) params.n_threads = atoi(argv[++i]);
+        else if ((arg == "-p" || arg == "--prompt") && has_value) params.prompt = argv[++i];
+        else if (arg == "--port" && has_value) params.port = atoi(argv[++i]);
+        else if ((arg == "-m" || arg == "--model") && has_value) params.model = argv[++i];
+        else {
+            if (arg != "-h" && arg != "--help") fprintf(stderr, "error: unknown argument: %s\n", arg.c_str());
+            usage();
+            exit(0);   // the reference exits with status 0 on both paths (bert.cpp:180-189)
+        }
+    }
+    return true;
+}
+
+struct bert_ctx *bert_load_from_file(const char *fname) { return load_impl(fname, false); }
+
+void bert_free(struct bert_ctx *ctx) { delete ctx; }
+
+int32_t bert_n_embd(struct bert_ctx *ctx) { return ctx->hp.n_embd; }
+int32_t bert_n_max_tokens(struct bert_ctx *ctx) { return ctx->hp.n_max_tokens; }
+const char *bert_vocab_id_to_token(struct bert_ctx *ctx, bert_vocab_id id) { return ctx->tok.id_to_token(id); }
+
+void bert_tokenize(struct bert_ctx *ctx, const char *text, bert_vocab_id *tokens, int32_t *n_tokens, int32_t n_max_tokens) {
+    ctx->tok.tokenize(text, tokens, n_tokens, n_max_tokens);
+}
+
+void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batch_size, bert_vocab_id **batch_tokens,
+                     int32_t *n_tokens, float **batch_embeddings) {
+    if (!batch_embeddings) return;   // the reference's memory-probe mode (bert.cpp:739); nothing to size here
+    if (!ctx->engine) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return; }
+    if (n_batch_size <= 0) return;
+    // The reference evaluates sentences in order and stops at the first one it cannot handle,
+    // leaving later outputs untouched; keep that observable behaviour.
+    int32_t B = 0;
+    for (; B < n_batch_size; ++B)
+        if (!sentence_ok(ctx, batch_tokens[B], n_tokens[B])) break;
+    if (B == 0) return;
+    std::vector<int32_t> cu(B + 1, 0);
+    for (int32_t b = 0; b < B; ++b) cu[b + 1] = cu[b] + n_tokens[b];
+    std::vector<int32_t> packed((size_t)cu[B]);
+    for (int32_t b = 0; b < B; ++b) memcpy(packed.data() + cu[b], batch_tokens[b], sizeof(int32_t) * n_tokens[b]);
+    const int H = ctx->hp.n_embd;
+    std::vector<float> out((size_t)B * H);
+    std::string err;
+    if (ctx->engine->eval_packed_host(packed.data(), cu.data(), B, out.data(), err) != 0) {
+        fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
+        return;
+    }
+    for (int32_t b = 0; b < B; ++b) memcpy(batch_embeddings[b], out.data() + (size_t)b * H, sizeof(float) * H);
+}
+
+void bert_eval(struct bert_ctx *ctx, int32_t n_threads, bert_vocab_id *tokens, int32_t n_tokens, float *embeddings) {
+    bert_eval_batch(ctx, n_threads, 1, &tokens, &n_tokens, embeddings ? &embeddings : nullptr);
+}
+
+void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batch_size*/, int32_t n_inputs,
+                       const char **texts, float **embeddings) {
+    if (n_inputs <= 0) return;
+    const int32_t N = ctx->hp.n_max_tokens;
+    // tokenize everything, then evaluate as packed device batches (the reference sorts by length and
+    // loops with batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching)
+    std::vector<bert_vocab_id> buf((size_t)N * n_inputs);
+    std::vector<int32_t> n_tokens(n_inputs);
+    std::vector<bert_vocab_id *> ptrs(n_inputs);
+    bert_vocab_id *it = buf.data();
+    for (int32_t i = 0; i < n_inputs; ++i) {
+        ptrs[i] = it;
+        ctx->tok.tokenize(texts[i], it, &n_tokens[i], N);
+        it += n_tokens[i];
+    }
+    bert_eval_batch(ctx, n_threads, n_inputs, ptrs.data(), n_tokens.data(), embeddings);
+}
+
+void bert_encode(struct bert_ctx *ctx, int32_t n_threads, const char *texts, float *embeddings) {
+    bert_encode_batch(ctx, n_threads, 1, 1, &texts, &embeddings);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bert_hip.h
+// ------------------------------------------------------------------------------------------------
+struct bert_ctx *bert_hip_load_tokenizer(const char *fname) { return load_impl(fname, true); }
+
+int32_t bert_hip_n_layer(struct bert_ctx *ctx) { return ctx->hp.n_layer; }
+int32_t bert_hip_n_head(struct bert_ctx *ctx) { return ctx->hp.n_head; }
+int32_t bert_hip_n_intermediate(struct bert_ctx *ctx) { return ctx->hp.n_intermediate; }
+int32_t bert_hip_n_vocab(struct bert_ctx *ctx) { return ctx->hp.n_vocab; }
+int32_t bert_hip_ftype(struct bert_ctx *ctx) { return ctx->hp.f16; }
+int32_t bert_hip_device(struct bert_ctx *ctx) { return ctx->engine ? ctx->engine->device() : -1; }
+
+int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens, const int32_t *cu_seqlens,
+                             int32_t n_sentences, float *embeddings) {
+    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_packed: tokenizer-only context\n"); return -1; }
+    for (int32_t b = 0; b < n_sentences; ++b)
+        if (!sentence_ok(ctx, tokens + cu_seqlens[b], cu_seqlens[b + 1] - cu_seqlens[b])) return -2;
+    std::string err;
+    if (ctx->engine->eval_packed_host(tokens, cu_seqlens, n_sentences, embeddings, err) != 0) {
+        fprintf(stderr, "bert_hip_eval_packed: %s\n", err.c_str());
+        return -3;
+    }
+    return 0;
+}
+
+int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens, const int32_t *d_cu_seqlens,
+                                    int32_t n_sentences, int32_t n_tokens_total, int32_t max_len, float *d_embeddings,
+                                    void *stream) {
+    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_packed_device: tokenizer-only context\n"); return -1; }
+    if (max_len > ctx->hp.n_max_tokens) { fprintf(stderr, "Too many tokens, maximum is %d\n", ctx->hp.n_max_tokens); return -2; }
+    std::string err;
+    if (ctx->engine->eval_packed_device(d_tokens, d_cu_seqlens, n_sentences, n_tokens_total, max_len, d_embeddings,
+                                        (hipStream_t)stream, nullptr, err) != 0) {
+        fprintf(stderr, "bert_hip_eval_packed_device: %s\n", err.c_str());
+        return -3;
+    }
+    return 0;
+}
+
+int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id *tokens, int32_t n_tokens, float *hidden,
+                             float *embedding) {
+    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_hidden: tokenizer-only context\n"); return -1; }
+    if (!sentence_ok(ctx, tokens, n_tokens)) return -2;
+    std::string err;
+    if (ctx->engine->eval_hidden(tokens, n_tokens, hidden, embedding, err) != 0) {
+        fprintf(stderr, "bert_hip_eval_hidden: %s\n", err.c_str());
+        return -3;
+    }
+    return 0;
+}
+
+void bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on) {
+    if (ctx->engine) ctx->engine->profile_enable(on != 0);
+}
+
+int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len) {
+    if (!ctx->engine) return 0;
+    const std::string r = ctx->engine->profile_report();
+    if (buf && buf_len > 0) {
+        const size_t n = std::min((size_t)buf_len - 1, r.size());
+        memcpy(buf, r.data(), n);
+        buf[n] = 0;
+    }
+    return (int32_t)r.size();
+}
+
+void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value) {
+    if (ctx->engine && key && value) ctx->engine->set_option(key, value);
+}
+
+const char *bert_hip_version(void) { return "bert.cpp_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// engine.h — device side of a bert_ctx: HBM-resident weights, workspace, and the launch sequence
+// of the forward pass.  Replaces the reference's ggml arena + per-sentence graph build + execute
+// (reference bert.cpp:730-941, sizing :680-713) with a fixed 2 + 7*L kernel sequence over a packed
+// variable-length batch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model_file.h"
+
+namespace bert_hip {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf();
+    bool alloc(size_t n, std::string &err);                       // zero-filled
+    bool upload(const void *src, size_t n, std::string &err);     // alloc + H2D
+    bool ensure(size_t n, std::string &err);                      // grow only
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// Owns the HBM image of one weight matrix in the layouts kernels.h describes.
+struct GemmWeightStore {
+    GemmWeight w;
+    DevBuf w16, qs, sc, naive16;
+    bool mfma_ok = false;
+    // rows: list of (file tensor) stacked along N (one entry, or q|k|v).  All share type and K.
+    bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err);
+};
+
+struct LayerWeights {
+    GemmWeightStore qkv, o, ffi, ffo;
+    DevBuf qkv_b, o_b, ffi_b, ffo_b, ln_att_w, ln_att_b, ln_out_w, ln_out_b;
+};
+
+struct KernelStat { int launches = 0; double ms = 0.0; double flops = 0.0; };
+
+class Engine {
+public:
+    static Engine *create(const ModelFile &mf, std::string &err);
+    ~Engine();
+
+    // host-resident packed batch (validated by the caller), blocking
+    int eval_packed_host(const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, float *embeddings,
+                         std::string &err);
+    // device-resident, asynchronous on `stream`
+    int eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int n_sentences, int n_tokens, int max_len,
+                           float *d_out, hipStream_t stream, float *d_hidden, std::string &err);
+    int eval_hidden(const int32_t *tokens, int n_tokens, float *hidden, float *embedding, std::string &err);
+
+    void set_option(const std::string &key, const std::string &value);
+    void profile_enable(bool on);
+    std::string profile_report();
+
+    const HParams &hparams() const { return hp_; }
+    int device() const { return device_; }
+
+private:
+    Engine() = default;
+    bool ensure_workspace(int t_pad, int n_sentences, std::string &err);
+    template <class F> void timed(const char *name, double flops, hipStream_t s, F &&f);
+
+    HParams hp_;
+    int device_ = 0;
+    int table_type_ = 0;
+    DevBuf word_emb_, type_emb_, pos_emb_, ln_e_w_, ln_e_b_;
+    std::vector<LayerWeights *> layers_;
+
+    // workspace (grow-only)
+    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_;
+    int32_t *h_tokens_ = nullptr, *h_cu_ = nullptr;   // pinned staging
+    float *h_out_ = nullptr;
+    size_t h_tokens_cap_ = 0, h_cu_cap_ = 0, h_out_cap_ = 0;
+    hipStream_t stream_ = nullptr;
+
+    // options
+    bool gemm_naive_ = false, attn_naive_ = false;
+    int chunk_tokens_ = 262144;
+
+    // profiling
+    bool profiling_ = false;
+    std::vector<hipEvent_t> ev_pool_;
+    struct Pending { const char *name; hipEvent_t a, b; double flops; };
+    std::vector<Pending> pending_;
+    std::map<std::string, KernelStat> stats_;
+};
+
+}  // namespace bert_hip

@@ -1,0 +1,384 @@
+// engine.hip — see engine.h.
+#include "engine.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace bert_hip {
+
+#define HIP_OK(expr, errvar, ret)                                                                       \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) {                                                                        \
+            errvar = std::string(#expr) + ": " + hipGetErrorString(e__);                                \
+            return ret;                                                                                 \
+        }                                                                                               \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// DevBuf
+// ------------------------------------------------------------------------------------------------
+DevBuf::~DevBuf() {
+    if (p) (void)hipFree(p);
+}
+bool DevBuf::alloc(size_t n, std::string &err) {
+    if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+    if (n == 0) n = 16;
+    HIP_OK(hipMalloc(&p, n), err, false);
+    bytes = n;
+    HIP_OK(hipMemset(p, 0, n), err, false);
+    return true;
+}
+bool DevBuf::upload(const void *src, size_t n, std::string &err) {
+    if (!alloc(n, err)) return false;
+    if (n) HIP_OK(hipMemcpy(p, src, n, hipMemcpyHostToDevice), err, false);
+    return true;
+}
+bool DevBuf::ensure(size_t n, std::string &err) {
+    if (n <= bytes) return true;
+    return alloc(n + n / 8, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight repacking (host) -> HBM layouts of kernels.h
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+inline float h2f(uint16_t bits) { _Float16 h; memcpy(&h, &bits, 2); return (float)h; }
+
+// row `r` of a file tensor dequantised to f16 (exactly representable for f16 files; nearest for f32 / q4)
+void row_to_f16(const HostTensor &t, int64_t r, _Float16 *dst) {
+    const int64_t K = t.ne0;
+    const uint8_t *src = t.data + wtype_row_bytes(t.type, K) * (size_t)r;
+    if (t.type == W_F32) {
+        const float *f = (const float *)src;
+        for (int64_t k = 0; k < K; ++k) dst[k] = (_Float16)f[k];
+    } else if (t.type == W_F16) {
+        memcpy(dst, src, (size_t)K * 2);
+    } else {
+        const int bs = t.type == W_Q4_0 ? 18 : 20;
+        for (int64_t b = 0; b < K / 32; ++b) {
+            const uint8_t *blk = src + b * bs;
+            uint16_t dbits; memcpy(&dbits, blk, 2);
+            const float d = h2f(dbits);
+            float m = 0.f;
+            const uint8_t *qs = blk + 2;
+            if (t.type == W_Q4_1) { uint16_t mb; memcpy(&mb, blk + 2, 2); m = h2f(mb); qs = blk + 4; }
+            for (int j = 0; j < 16; ++j) {
+                const int q0 = qs[j] & 0x0F, q1 = qs[j] >> 4;
+                if (t.type == W_Q4_0) {
+                    dst[b * 32 + j] = (_Float16)((float)(q0 - 8) * d);
+                    dst[b * 32 + j + 16] = (_Float16)((float)(q1 - 8) * d);
+                } else {
+                    dst[b * 32 + j] = (_Float16)((float)q0 * d + m);
+                    dst[b * 32 + j + 16] = (_Float16)((float)q1 * d + m);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err) {
+    const int64_t K = rows[0]->ne0;
+    const int ftype = rows[0]->type;
+    int64_t N = 0;
+    for (auto *t : rows) {
+        if (t->ne0 != K || t->type != ftype) { err = "stacked weights disagree in shape/type"; return false; }
+        N += t->ne1;
+    }
+    w.N = (int)N; w.K = (int)K;
+    w.N_pad = (int)((N + GEMM_BN - 1) / GEMM_BN * GEMM_BN);
+    mfma_ok = (K % GEMM_BK == 0) && (N % 8 == 0);
+    auto src_row = [&](int64_t n, const HostTensor *&t, int64_t &r) {
+        for (auto *c : rows) { if (n < c->ne1) { t = c; r = n; return; } n -= c->ne1; }
+        t = nullptr; r = 0;
+    };
+    const bool quant = ftype == W_Q4_0 || ftype == W_Q4_1;
+    if (mfma_ok && !quant) {
+        w.type = GW_F16;
+        std::vector<_Float16> img((size_t)w.N_pad * K, (_Float16)0);
+        for (int64_t n = 0; n < N; ++n) { const HostTensor *t; int64_t r; src_row(n, t, r); row_to_f16(*t, r, img.data() + (size_t)n * K); }
+        if (!w16.upload(img.data(), img.size() * 2, err)) return false;
+        w.w16 = w16.as<half_t>();
+    } else if (mfma_ok) {
+        w.type = ftype == W_Q4_0 ? GW_Q4_0 : GW_Q4_1;
+        const int bs = ftype == W_Q4_0 ? 18 : 20, scb = ftype == W_Q4_0 ? 2 : 4;
+        const int64_t nkt = K / GEMM_BK, ntn = w.N_pad / GEMM_BN;
+        const size_t nblk = (size_t)ntn * nkt * 256;
+        std::vector<uint8_t> q(nblk * 16, 0), s(nblk * scb, 0);
+        for (int64_t nt = 0; nt < ntn; ++nt)
+            for (int64_t kt = 0; kt < nkt; ++kt)
+                for (int row = 0; row < 128; ++row) {
+                    const int64_t n = nt * 128 + row;
+                    if (n >= N) continue;
+                    const HostTensor *t; int64_t r; src_row(n, t, r);
+                    const uint8_t *rowp = t->data + wtype_row_bytes(ftype, K) * (size_t)r;
+                    for (int kb = 0; kb < 2; ++kb) {
+                        const uint8_t *blk = rowp + (size_t)(kt * 2 + kb) * bs;
+                        const size_t bi = ((size_t)(nt * nkt + kt) * 128 + row) * 2 + kb;
+                        memcpy(s.data() + bi * scb, blk, scb);               // d  or  {d, m}
+                        memcpy(q.data() + bi * 16, blk + scb, 16);           // 32 nibbles
+                    }
+                }
+        if (!qs.upload(q.data(), q.size(), err) || !sc.upload(s.data(), s.size(), err)) return false;
+        w.qs = qs.as<uint4>();
+        w.sc = sc.p;
+    }
+    if (!mfma_ok || want_naive) {
+        std::vector<_Float16> img((size_t)N * K);
+        for (int64_t n = 0; n < N; ++n) { const HostTensor *t; int64_t r; src_row(n, t, r); row_to_f16(*t, r, img.data() + (size_t)n * K); }
+        if (!naive16.upload(img.data(), img.size() * 2, err)) return false;
+        w.naive16 = naive16.as<half_t>();
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Engine
+// ------------------------------------------------------------------------------------------------
+static bool upload_f32(DevBuf &b, const HostTensor *t, std::string &err) { return b.upload(t->data, t->nbytes, err); }
+
+static bool concat_upload(DevBuf &b, std::initializer_list<const HostTensor *> ts, std::string &err) {
+    std::vector<uint8_t> all;
+    for (auto *t : ts) all.insert(all.end(), t->data, t->data + t->nbytes);
+    return b.upload(all.data(), all.size(), err);
+}
+
+Engine *Engine::create(const ModelFile &mf, std::string &err) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        err = "no HIP device available (this library needs an AMD GPU; there is no CPU fallback)";
+        return nullptr;
+    }
+    Engine *e = new Engine;
+    e->hp_ = mf.hp;
+    const char *dv = getenv("BERT_HIP_DEVICE");
+    if (dv && *dv) {
+        e->device_ = atoi(dv);
+        if (e->device_ < 0 || e->device_ >= ndev) { err = "BERT_HIP_DEVICE out of range"; delete e; return nullptr; }
+        if (hipSetDevice(e->device_) != hipSuccess) { err = "hipSetDevice failed"; delete e; return nullptr; }
+    } else if (hipGetDevice(&e->device_) != hipSuccess) { err = "hipGetDevice failed"; delete e; return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, e->device_) != hipSuccess) { err = "hipGetDeviceProperties failed"; delete e; return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        err = std::string("unsupported GPU architecture '") + prop.gcnArchName + "' (kernels are built for gfx950 / MI355X only)";
+        delete e; return nullptr;
+    }
+    if (const char *g = getenv("BERT_HIP_GEMM")) e->gemm_naive_ = strcmp(g, "naive") == 0;
+    if (const char *a = getenv("BERT_HIP_ATTN")) e->attn_naive_ = strcmp(a, "naive") == 0;
+    if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
+    if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
+
+    auto T = [&](const std::string &n) { return mf.find(n); };
+    bool ok = true;
+    e->table_type_ = mf.hp.f16;
+    ok = ok && upload_f32(e->word_emb_, T("embeddings.word_embeddings.weight"), err);
+    ok = ok && upload_f32(e->type_emb_, T("embeddings.token_type_embeddings.weight"), err);
+    ok = ok && upload_f32(e->pos_emb_, T("embeddings.position_embeddings.weight"), err);
+    ok = ok && upload_f32(e->ln_e_w_, T("embeddings.LayerNorm.weight"), err);
+    ok = ok && upload_f32(e->ln_e_b_, T("embeddings.LayerNorm.bias"), err);
+    const bool want_naive = e->gemm_naive_;
+    for (int i = 0; ok && i < mf.hp.n_layer; ++i) {
+        const std::string p = "encoder.layer." + std::to_string(i) + ".";
+        auto *L = new LayerWeights;
+        e->layers_.push_back(L);
+        ok = ok && L->qkv.build({T(p + "attention.self.query.weight"), T(p + "attention.self.key.weight"),
+                                 T(p + "attention.self.value.weight")}, want_naive, err);
+        ok = ok && concat_upload(L->qkv_b, {T(p + "attention.self.query.bias"), T(p + "attention.self.key.bias"),
+                                            T(p + "attention.self.value.bias")}, err);
+        ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err);
+        ok = ok && upload_f32(L->o_b, T(p + "attention.output.dense.bias"), err);
+        ok = ok && upload_f32(L->ln_att_w, T(p + "attention.output.LayerNorm.weight"), err);
+        ok = ok && upload_f32(L->ln_att_b, T(p + "attention.output.LayerNorm.bias"), err);
+        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err);
+        ok = ok && upload_f32(L->ffi_b, T(p + "intermediate.dense.bias"), err);
+        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err);
+        ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
+        ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
+        ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
+    }
+    if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
+    if (!ok) { delete e; return nullptr; }
+    return e;
+}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (auto *L : layers_) delete L;
+    for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
+    for (auto &p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    if (h_tokens_) (void)hipHostFree(h_tokens_);
+    if (h_cu_) (void)hipHostFree(h_cu_);
+    if (h_out_) (void)hipHostFree(h_out_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void Engine::set_option(const std::string &key, const std::string &value) {
+    if (key == "gemm") {
+        gemm_naive_ = value == "naive";
+    } else if (key == "attn") attn_naive_ = value == "naive";
+    else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
+}
+
+bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
+    const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
+    return x_.ensure(tp * H * 2, err) && qkv_.ensure(tp * 3 * H * 2, err) && ctx_.ensure(tp * H * 2, err) &&
+           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && d_out_.ensure((size_t)n_sentences * H * 4, err);
+}
+
+template <class F>
+void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
+    if (!profiling_) { f(); return; }
+    auto get = [&]() {
+        hipEvent_t ev;
+        if (!ev_pool_.empty()) { ev = ev_pool_.back(); ev_pool_.pop_back(); }
+        else (void)hipEventCreate(&ev);
+        return ev;
+    };
+    Pending p{name, get(), get(), flops};
+    (void)hipEventRecord(p.a, s);
+    f();
+    (void)hipEventRecord(p.b, s);
+    pending_.push_back(p);
+}
+
+void Engine::profile_enable(bool on) { profiling_ = on; }
+
+std::string Engine::profile_report() {
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (auto &p : pending_) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            KernelStat &st = stats_[p.name];
+            st.launches += 1; st.ms += ms; st.flops += p.flops;
+        }
+        ev_pool_.push_back(p.a); ev_pool_.push_back(p.b);
+    }
+    pending_.clear();
+    std::string out;
+    char line[256];
+    for (auto &kv : stats_) {
+        snprintf(line, sizeof(line), "%s %d %.6f %.6e\n", kv.first.c_str(), kv.second.launches, kv.second.ms,
+                 kv.second.launches ? kv.second.flops / kv.second.launches : 0.0);
+        out += line;
+    }
+    stats_.clear();
+    return out;
+}
+
+int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int B, int T, int max_len, float *d_out,
+                               hipStream_t s, float *d_hidden, std::string &err) {
+    if (B <= 0 || T <= 0) return 0;
+    HIP_OK(hipSetDevice(device_), err, -1);
+    const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
+    const int t_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    if (!ensure_workspace(t_pad, B, err)) return -1;
+    half_t *x = x_.as<half_t>(), *qkv = qkv_.as<half_t>(), *ctx = ctx_.as<half_t>(), *y = y_.as<half_t>(),
+           *ff = ff_.as<half_t>();
+    const double Td = (double)T;
+
+    auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
+                    half_t *C, int epi) {
+        timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
+            if (W.mfma_ok && !gemm_naive_) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
+            else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
+        });
+    };
+    auto tap = [&](int idx) {
+        if (d_hidden) launch_f16_to_f32(x, d_hidden + (size_t)idx * T * H, (size_t)T * H, s);
+    };
+
+    timed("embed_ln", 0.0, s, [&] {
+        launch_embed_ln(word_emb_.p, type_emb_.p, pos_emb_.p, table_type_, ln_e_w_.as<float>(), ln_e_b_.as<float>(),
+                        d_tokens, d_cu, B, T, H, hp_.n_vocab, x, s);
+    });
+    tap(0);
+    // attention FLOPs: 4 * sum_b N_b^2 * H; only T and max_len are known here -> upper bound T * max_len
+    const double att_flops = 4.0 * Td * max_len * H;
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        LayerWeights &L = *layers_[il];
+        gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
+        timed("attention", att_flops, s, [&] {
+            if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
+                launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
+        });
+        gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
+        timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
+        gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
+        gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
+        timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+        tap(il + 1);
+    }
+    timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, d_out, s); });
+    (void)I;
+    HIP_OK(hipGetLastError(), err, -1);
+    return 0;
+}
+
+static bool ensure_pinned(void **p, size_t *cap, size_t need, std::string &err) {
+    if (need <= *cap) return true;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    need += need / 4;
+    HIP_OK(hipHostMalloc(p, need, hipHostMallocDefault), err, false);
+    *cap = need;
+    return true;
+}
+
+int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, float *embeddings, std::string &err) {
+    if (B <= 0) return 0;
+    HIP_OK(hipSetDevice(device_), err, -1);
+    const int H = hp_.n_embd;
+    int b0 = 0;
+    while (b0 < B) {
+        // chunk [b0, b1): at most chunk_tokens_ tokens, at least one sentence
+        int b1 = b0 + 1, max_len = cu[b0 + 1] - cu[b0];
+        while (b1 < B && cu[b1 + 1] - cu[b0] <= chunk_tokens_) { max_len = std::max(max_len, cu[b1 + 1] - cu[b1]); ++b1; }
+        const int nb = b1 - b0, T = cu[b1] - cu[b0];
+        if (!ensure_pinned((void **)&h_tokens_, &h_tokens_cap_, (size_t)T * 4, err)) return -1;
+        if (!ensure_pinned((void **)&h_cu_, &h_cu_cap_, (size_t)(nb + 1) * 4, err)) return -1;
+        if (!ensure_pinned((void **)&h_out_, &h_out_cap_, (size_t)nb * H * 4, err)) return -1;
+        if (!d_tokens_.ensure((size_t)T * 4, err) || !d_cu_.ensure((size_t)(nb + 1) * 4, err)) return -1;
+        memcpy(h_tokens_, tokens + cu[b0], (size_t)T * 4);
+        for (int i = 0; i <= nb; ++i) h_cu_[i] = cu[b0 + i] - cu[b0];
+        const int t_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+        if (!ensure_workspace(t_pad, nb, err)) return -1;
+        HIP_OK(hipMemcpyAsync(d_tokens_.p, h_tokens_, (size_t)T * 4, hipMemcpyHostToDevice, stream_), err, -1);
+        HIP_OK(hipMemcpyAsync(d_cu_.p, h_cu_, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_), err, -1);
+        if (eval_packed_device(d_tokens_.as<int32_t>(), d_cu_.as<int32_t>(), nb, T, max_len, d_out_.as<float>(), stream_,
+                               nullptr, err) != 0)
+            return -1;
+        HIP_OK(hipMemcpyAsync(h_out_, d_out_.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_), err, -1);
+        HIP_OK(hipStreamSynchronize(stream_), err, -1);
+        memcpy(embeddings + (size_t)b0 * H, h_out_, (size_t)nb * H * 4);
+        b0 = b1;
+    }
+    return 0;
+}
+
+int Engine::eval_hidden(const int32_t *tokens, int N, float *hidden, float *embedding, std::string &err) {
+    HIP_OK(hipSetDevice(device_), err, -1);
+    const int H = hp_.n_embd, L = hp_.n_layer;
+    int32_t cu[2] = {0, N};
+    if (!d_tokens_.ensure((size_t)N * 4, err) || !d_cu_.ensure(8, err)) return -1;
+    if (!d_hidden_.ensure((size_t)(L + 1) * N * H * 4, err)) return -1;
+    const int t_pad = (N + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    if (!ensure_workspace(t_pad, 1, err)) return -1;
+    HIP_OK(hipMemcpy(d_tokens_.p, tokens, (size_t)N * 4, hipMemcpyHostToDevice), err, -1);
+    HIP_OK(hipMemcpy(d_cu_.p, cu, 8, hipMemcpyHostToDevice), err, -1);
+    if (eval_packed_device(d_tokens_.as<int32_t>(), d_cu_.as<int32_t>(), 1, N, N, d_out_.as<float>(), stream_,
+                           d_hidden_.as<float>(), err) != 0)
+        return -1;
+    HIP_OK(hipStreamSynchronize(stream_), err, -1);
+    if (hidden) HIP_OK(hipMemcpy(hidden, d_hidden_.p, (size_t)(L + 1) * N * H * 4, hipMemcpyDeviceToHost), err, -1);
+    if (embedding) HIP_OK(hipMemcpy(embedding, d_out_.p, (size_t)H * 4, hipMemcpyDeviceToHost), err, -1);
+    return 0;
+}
+
+}  // namespace bert_hip

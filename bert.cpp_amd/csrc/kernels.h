@@ -1,0 +1,66 @@
+// kernels.h — launch interface of the HIP kernels of the bert_eval hot path (gfx950 only).
+//
+// Reference ops each kernel replaces are listed in SURVEY.md §2.3; call sites bert.cpp:796-913.
+// Activations are f16 row-major [T_pad][features]; T_pad is T rounded up to GEMM_BM tokens.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace bert_hip {
+
+typedef _Float16 half_t;
+
+constexpr int GEMM_BM = 128;   // token tile
+constexpr int GEMM_BN = 128;   // feature tile
+constexpr int GEMM_BK = 64;    // reduction tile (two 32-weight quant blocks)
+
+enum Epilogue : int { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
+enum GemmWType : int { GW_F16 = 0, GW_Q4_0 = 1, GW_Q4_1 = 2 };
+
+// A weight matrix W[N][K] (out-features x in-features) in its HBM layout.
+//   GW_F16 : w16  [N_pad][K] f16 row-major (rows N..N_pad are zero)
+//   GW_Q4_x: qs   one uint4 (16 B of nibbles) per 32-weight block, tile-contiguous:
+//                 index = ((nt * (K/64) + kt) * 128 + row_in_tile) * 2 + block_in_ktile
+//            sc   f16 scale per block (q4_0) or f16x2 {d, m} per block (q4_1), same order
+//   naive16: optional f16 [N][K] row-major dequantised copy used by the generic fallback kernel
+struct GemmWeight {
+    int N = 0, K = 0, N_pad = 0;
+    int type = GW_F16;
+    const half_t *w16 = nullptr;
+    const uint4 *qs = nullptr;
+    const void *sc = nullptr;
+    const half_t *naive16 = nullptr;
+};
+
+// C[t][n] = epi( sum_k A[t][k] * W[n][k] + bias[n] (+ resid[t][n]) ), t < M_pad (multiple of 128)
+// lda = K, ldc = ldr = N.  MFMA path requires K % 64 == 0.
+void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
+                      int M_pad, int epilogue, hipStream_t stream);
+// Generic fallback (any K, N); needs W.naive16.
+void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
+                       int M, int epilogue, hipStream_t stream);
+
+// word + token_type(0) + position gather-sum, LayerNorm(eps 1e-5), f16 out.  Tables in file layout.
+void launch_embed_ln(const void *word, const void *type, const void *pos, int table_type, const float *gamma,
+                     const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
+                     int H, int n_vocab, half_t *out, hipStream_t stream);
+
+// In-place LayerNorm over H of f16 rows (eps 1e-5), gamma/beta f32.
+void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, int H, hipStream_t stream);
+
+// qkv [T_pad][3H] (Q | K | V), packed sentences; out ctx [T_pad][H].
+// MFMA path supports d_head in {32, 64}; returns false if the shape needs the naive kernel.
+bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
+                           int max_len, half_t *out, hipStream_t stream);
+void launch_attention_naive(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
+                            int max_len, half_t *out, hipStream_t stream);
+
+// mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].
+void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
+                           hipStream_t stream);
+
+// f16 [rows][cols] -> f32 (hidden-state tap)
+void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream);
+
+}  // namespace bert_hip

@@ -1,0 +1,173 @@
+// misc_kernels.hip — the HBM-bound pieces of the forward pass (gfx950): embedding gather-sum +
+// LayerNorm, stand-alone LayerNorm, mean-pool + L2 normalise.  One 64-lane wavefront per token row
+// with __shfl_xor reductions; no LDS needed.
+#include "kernels.h"
+
+namespace bert_hip {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Element e of row r of an embedding table stored in the model-file layout,
+// dequantised to f32 exactly as ggml_get_rows does: f16 -> f32, (q-8)*d, q*d+m.
+__device__ __forceinline__ float table_elem(const void *tab, int type, int H, int r, int e) {
+    if (type == 0) return ((const float *)tab)[(size_t)r * H + e];
+    if (type == 1) return (float)((const half_t *)tab)[(size_t)r * H + e];
+    const int bs = type == 2 ? 18 : 20;
+    const unsigned char *blk = (const unsigned char *)tab + ((size_t)r * (H / 32) + e / 32) * bs;
+    const int i = e & 31;
+    const float d = (float)*(const half_t *)blk;
+    const unsigned char byte = blk[(type == 2 ? 2 : 4) + (i & 15)];
+    const int q = i < 16 ? (byte & 0x0F) : (byte >> 4);
+    if (type == 2) return (float)(q - 8) * d;
+    const float m = (float)*(const half_t *)(blk + 2);
+    return (float)q * d + m;
+}
+
+// reference bert.cpp:796-814: inpL = word[ids]; inpL = type[0] + inpL; inpL = pos[0..N-1] + inpL;
+// LayerNorm (ggml_norm eps 1e-5) then gamma * x + beta.
+__global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const void *type, const void *pos,
+                                                       int table_type, const float *gamma, const float *beta,
+                                                       const int32_t *tokens, const int32_t *cu_seqlens,
+                                                       int n_sentences, int T, int H, int n_vocab, half_t *out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    // sentence of token t: largest b with cu[b] <= t
+    int lo = 0, hi = n_sentences;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (cu_seqlens[mid] <= t) lo = mid; else hi = mid;
+    }
+    const int p = t - cu_seqlens[lo];
+    int id = tokens[t];
+    id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);   // ids are validated on the host API; clamp for safety
+
+    float sum = 0.f;
+    for (int e = lane; e < H; e += 64) {
+        float v = table_elem(word, table_type, H, id, e);
+        v = table_elem(type, table_type, H, 0, e) + v;
+        v = table_elem(pos, table_type, H, p, e) + v;
+        sum += v;
+    }
+    const float mean = wave_sum(sum) / H;
+    float sq = 0.f;
+    for (int e = lane; e < H; e += 64) {
+        float v = table_elem(word, table_type, H, id, e);
+        v = table_elem(type, table_type, H, 0, e) + v;
+        v = table_elem(pos, table_type, H, p, e) + v;
+        v -= mean;
+        sq += v * v;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / H + 1e-5f);
+    for (int e = lane; e < H; e += 64) {
+        float v = table_elem(word, table_type, H, id, e);
+        v = table_elem(type, table_type, H, 0, e) + v;
+        v = table_elem(pos, table_type, H, p, e) + v;
+        out[(size_t)t * H + e] = (_Float16)(gamma[e] * ((v - mean) * rstd) + beta[e]);
+    }
+}
+
+void launch_embed_ln(const void *word, const void *type, const void *pos, int table_type, const float *gamma,
+                     const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
+                     int H, int n_vocab, half_t *out, hipStream_t stream) {
+    if (T <= 0) return;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, word, type, pos, table_type, gamma,
+                       beta, tokens, cu_seqlens, n_sentences, T, H, n_vocab, out);
+}
+
+// reference bert.cpp:868-874 / :894-900 (ggml_norm + gamma/beta), in place on f16 rows.
+// NJ = pairs per lane held in registers (H <= 128 * NJ).
+template <int NJ>
+__global__ __launch_bounds__(256) void layernorm_kernel(half_t *x, const float *gamma, const float *beta, int T, int H) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T) return;
+    half_t *row = x + (size_t)t * H;
+    float v[NJ][2];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        if (e < H) {
+            const f16x2 h2 = *(const f16x2 *)(row + e);
+            v[j][0] = (float)h2[0]; v[j][1] = (float)h2[1];
+        } else { v[j][0] = 0.f; v[j][1] = 0.f; }
+        sum += v[j][0] + v[j][1];
+    }
+    const float mean = wave_sum(sum) / H;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        if (e < H) {
+            v[j][0] -= mean; v[j][1] -= mean;
+            sq += v[j][0] * v[j][0] + v[j][1] * v[j][1];
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / H + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        if (e < H) {
+            f16x2 o;
+            o[0] = (_Float16)(gamma[e] * (v[j][0] * rstd) + beta[e]);
+            o[1] = (_Float16)(gamma[e + 1] * (v[j][1] * rstd) + beta[e + 1]);
+            *(f16x2 *)(row + e) = o;
+        }
+    }
+}
+
+void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, int H, hipStream_t stream) {
+    if (T <= 0) return;
+    const dim3 grid((T + 3) / 4), block(256);
+    const int nj = (H + 127) / 128;      // H must be even (checked at load)
+    if (nj <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else hipLaunchKernelGGL(layernorm_kernel<32>, grid, block, 0, stream, x, gamma, beta, T, H);   // H <= 4096
+}
+
+// reference bert.cpp:904-913: mean over all N tokens (mat-vec with a 1/N vector), then y / ||y||_2.
+__global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, const int32_t *cu_seqlens, int H,
+                                                             float *out) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
+    const float invn = 1.0f / (float)n;
+    float sq = 0.f;
+    for (int e = tid; e < H; e += 256) {
+        float a = 0.f;
+        for (int t = 0; t < n; ++t) a += (float)x[(size_t)(tok0 + t) * H + e] * invn;
+        out[(size_t)b * H + e] = a;
+        sq += a * a;
+    }
+    sq = wave_sum(sq);
+    if ((tid & 63) == 0) red[tid >> 6] = sq;
+    __syncthreads();
+    const float len2 = red[0] + red[1] + red[2] + red[3];
+    const float scale = 1.0f / sqrtf(len2);
+    for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] *= scale;
+}
+
+void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
+                           hipStream_t stream) {
+    if (n_sentences <= 0) return;
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_sentences), dim3(256), 0, stream, x, cu_seqlens, H, out);
+}
+
+__global__ void f16_to_f32_kernel(const half_t *src, float *dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (float)src[i];
+}
+
+void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream) {
+    if (!n) return;
+    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+}
+
+}  // namespace bert_hip

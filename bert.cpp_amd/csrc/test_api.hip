@@ -1,0 +1,77 @@
+// test_api.hip — standalone kernel entry points of bert_hip.h for op-level parity tests.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bert_hip.h"
+#include "engine.h"
+
+using namespace bert_hip;
+
+#define CK(expr)                                                                       \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            fprintf(stderr, "%s: %s\n", #expr, hipGetErrorString(e__));                \
+            return -1;                                                                 \
+        }                                                                              \
+    } while (0)
+
+extern "C" {
+
+int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype,
+                           const float *bias, const uint16_t *resid, int32_t epilogue, int32_t impl, uint16_t *C) {
+    std::string err;
+    HostTensor t;
+    t.type = wtype; t.n_dims = 2; t.ne0 = K; t.ne1 = N; t.data = (const uint8_t *)W;
+    t.nbytes = wtype_row_bytes(wtype, K) * (size_t)N;
+    GemmWeightStore ws;
+    if (!ws.build({&t}, impl == 1, err)) { fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str()); return -1; }
+    if (impl == 0 && !ws.mfma_ok) { fprintf(stderr, "bert_hip_test_gemm: shape not supported by the MFMA path\n"); return -2; }
+    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    DevBuf dA, dB, dR, dC;
+    if (!dA.alloc((size_t)M_pad * K * 2, err) || !dC.alloc((size_t)M_pad * N * 2, err) || !dB.upload(bias, (size_t)N * 4, err)) {
+        fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str());
+        return -1;
+    }
+    CK(hipMemcpy(dA.p, A, (size_t)M * K * 2, hipMemcpyHostToDevice));
+    if (resid) {
+        if (!dR.alloc((size_t)M_pad * N * 2, err)) return -1;
+        CK(hipMemcpy(dR.p, resid, (size_t)M * N * 2, hipMemcpyHostToDevice));
+    }
+    if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
+    else launch_gemm_naive(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M, epilogue, nullptr);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(C, dC.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
+                                const uint16_t *qkv, int32_t impl, uint16_t *out) {
+    std::string err;
+    const int T = cu_seqlens[n_sentences], H = n_head * d_head;
+    int max_len = 0;
+    for (int b = 0; b < n_sentences; ++b) max_len = std::max(max_len, cu_seqlens[b + 1] - cu_seqlens[b]);
+    DevBuf dq, dcu, dout;
+    if (!dq.upload(qkv, (size_t)T * 3 * H * 2, err) || !dcu.upload(cu_seqlens, (size_t)(n_sentences + 1) * 4, err) ||
+        !dout.alloc((size_t)T * H * 2, err)) {
+        fprintf(stderr, "bert_hip_test_attention: %s\n", err.c_str());
+        return -1;
+    }
+    if (impl == 0) {
+        if (!launch_attention_mfma(dq.as<half_t>(), dcu.as<int32_t>(), n_sentences, n_head, d_head, max_len, dout.as<half_t>(), nullptr)) {
+            fprintf(stderr, "bert_hip_test_attention: shape not supported by the MFMA path\n");
+            return -2;
+        }
+    } else {
+        launch_attention_naive(dq.as<half_t>(), dcu.as<int32_t>(), n_sentences, n_head, d_head, max_len, dout.as<half_t>(), nullptr);
+    }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)T * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+"""ctypes binding of libbert.so — the same way the reference's Python callers bind it
+(reference examples/sample_dylib.py:19-59, benchmarks/run_mteb.py:34-72), plus the bert_hip.h
+extensions.  There is no fallback: if the shared library (the HIP extension) is missing or does
+not load, importing/constructing fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbert.so")
+
+# every symbol include/bert.h and include/bert_hip.h declare
+BERT_H_SYMBOLS = [
+    "bert_params_parse", "bert_load_from_file", "bert_free", "bert_encode", "bert_encode_batch", "bert_tokenize",
+    "bert_eval", "bert_eval_batch", "bert_n_embd", "bert_n_max_tokens", "bert_vocab_id_to_token",
+]
+BERT_HIP_H_SYMBOLS = [
+    "bert_hip_load_tokenizer", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
+    "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
+    "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
+    "bert_hip_test_attention", "bert_hip_version",
+]
+
+
+def build(force: bool = False, jobs: int = 8) -> str:
+    """Compile libbert.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", _HERE, f"-j{jobs}", "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python -c 'import __graft_entry__ as g; g.build()' or make -C bert.cpp_amd)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.bert_load_from_file.restype = vp; L.bert_load_from_file.argtypes = [C.c_char_p]
+    L.bert_hip_load_tokenizer.restype = vp; L.bert_hip_load_tokenizer.argtypes = [C.c_char_p]
+    L.bert_free.restype = None; L.bert_free.argtypes = [vp]
+    for fn in ("bert_n_embd", "bert_n_max_tokens", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate",
+               "bert_hip_n_vocab", "bert_hip_ftype", "bert_hip_device"):
+        getattr(L, fn).restype = i32; getattr(L, fn).argtypes = [vp]
+    L.bert_vocab_id_to_token.restype = C.c_char_p; L.bert_vocab_id_to_token.argtypes = [vp, i32]
+    L.bert_tokenize.restype = None; L.bert_tokenize.argtypes = [vp, C.c_char_p, i32p, i32p, i32]
+    L.bert_eval.restype = None; L.bert_eval.argtypes = [vp, i32, i32p, i32, f32p]
+    L.bert_eval_batch.restype = None
+    L.bert_eval_batch.argtypes = [vp, i32, i32, C.POINTER(i32p), i32p, C.POINTER(f32p)]
+    L.bert_encode.restype = None; L.bert_encode.argtypes = [vp, i32, C.c_char_p, f32p]
+    L.bert_encode_batch.restype = None
+    L.bert_encode_batch.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_char_p), C.POINTER(f32p)]
+    L.bert_hip_eval_packed.restype = i32; L.bert_hip_eval_packed.argtypes = [vp, i32p, i32p, i32, f32p]
+    L.bert_hip_eval_packed_device.restype = i32
+    L.bert_hip_eval_packed_device.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    L.bert_hip_eval_hidden.restype = i32; L.bert_hip_eval_hidden.argtypes = [vp, i32p, i32, f32p, f32p]
+    L.bert_hip_profile_enable.restype = None; L.bert_hip_profile_enable.argtypes = [vp, i32]
+    L.bert_hip_profile_report.restype = i32; L.bert_hip_profile_report.argtypes = [vp, C.c_char_p, i32]
+    L.bert_hip_set_option.restype = None; L.bert_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.bert_hip_test_gemm.restype = i32
+    L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
+    L.bert_hip_test_attention.restype = i32
+    L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
+    L.bert_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _f32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i32p(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class BertModel:
+    """Mirror of the reference's Python `BertModel` wrapper (examples/sample_dylib.py:12-59)."""
+
+    def __init__(self, fname: str, tokenizer_only: bool = False):
+        self.lib = lib()
+        load = self.lib.bert_hip_load_tokenizer if tokenizer_only else self.lib.bert_load_from_file
+        self.ctx = load(fname.encode("utf-8"))
+        if not self.ctx:
+            raise RuntimeError(f"bert_load_from_file('{fname}') failed (see stderr)")
+        self.n_embd = self.lib.bert_n_embd(self.ctx)
+        self.n_max_tokens = self.lib.bert_n_max_tokens(self.ctx)
+        self.n_layer = self.lib.bert_hip_n_layer(self.ctx)
+        self.n_vocab = self.lib.bert_hip_n_vocab(self.ctx)
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.bert_free(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- bert.h ---------------------------------------------------------------------------
+    def tokenize(self, text: str | bytes, n_max_tokens: Optional[int] = None) -> List[int]:
+        n_max = n_max_tokens or self.n_max_tokens
+        buf = (C.c_int32 * max(n_max, 2))()
+        n = C.c_int32(0)
+        data = text if isinstance(text, bytes) else text.encode("utf-8")
+        self.lib.bert_tokenize(self.ctx, data, buf, C.byref(n), n_max)
+        return list(buf[: n.value])
+
+    def id_to_token(self, i: int) -> bytes:
+        return self.lib.bert_vocab_id_to_token(self.ctx, i)
+
+    def eval(self, tokens: Sequence[int], n_threads: int = 6) -> np.ndarray:
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.full(self.n_embd, np.nan, dtype=np.float32)
+        self.lib.bert_eval(self.ctx, n_threads, _i32p(toks), len(toks), _f32p(out))
+        return out
+
+    def eval_batch(self, sentences: Sequence[Sequence[int]], n_threads: int = 6) -> np.ndarray:
+        """bert_eval_batch through per-sentence host pointers, exactly like a C caller."""
+        B = len(sentences)
+        arrs = [np.ascontiguousarray(s, dtype=np.int32) for s in sentences]
+        out = np.full((B, self.n_embd), np.nan, dtype=np.float32)
+        tok_ptrs = (C.POINTER(C.c_int32) * B)(*[_i32p(a) for a in arrs])
+        lens = np.array([len(a) for a in arrs], dtype=np.int32)
+        out_ptrs = (C.POINTER(C.c_float) * B)(*[_f32p(out[i]) for i in range(B)])
+        self.lib.bert_eval_batch(self.ctx, n_threads, B, tok_ptrs, _i32p(lens), out_ptrs)
+        return out
+
+    def encode(self, text: str, n_threads: int = 6) -> np.ndarray:
+        out = np.full(self.n_embd, np.nan, dtype=np.float32)
+        self.lib.bert_encode(self.ctx, n_threads, text.encode("utf-8"), _f32p(out))
+        return out
+
+    def encode_batch(self, texts: Sequence[str], n_threads: int = 6, batch_size: int = 16) -> np.ndarray:
+        n = len(texts)
+        out = np.full((n, self.n_embd), np.nan, dtype=np.float32)
+        out_ptrs = (C.POINTER(C.c_float) * n)(*[_f32p(out[i]) for i in range(n)])
+        txt = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        self.lib.bert_encode_batch(self.ctx, n_threads, batch_size, n, txt, out_ptrs)
+        return out
+
+    # ---- bert_hip.h -----------------------------------------------------------------------
+    def eval_packed(self, tokens: np.ndarray, cu_seqlens: np.ndarray) -> np.ndarray:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        B = len(cu) - 1
+        out = np.full((B, self.n_embd), np.nan, dtype=np.float32)
+        r = self.lib.bert_hip_eval_packed(self.ctx, _i32p(tokens), _i32p(cu), B, _f32p(out))
+        if r != 0:
+            raise RuntimeError(f"bert_hip_eval_packed failed: {r}")
+        return out
+
+    def eval_packed_device(self, d_tokens_ptr: int, d_cu_ptr: int, n_sentences: int, n_tokens: int, max_len: int,
+                           d_out_ptr: int, stream: int = 0) -> None:
+        r = self.lib.bert_hip_eval_packed_device(self.ctx, d_tokens_ptr, d_cu_ptr, n_sentences, n_tokens, max_len,
+                                                 d_out_ptr, stream)
+        if r != 0:
+            raise RuntimeError(f"bert_hip_eval_packed_device failed: {r}")
+
+    def eval_hidden(self, tokens: Sequence[int]):
+        toks = np.ascontiguousarray(tokens, dtype=np.int32)
+        hid = np.empty((self.n_layer + 1, len(toks), self.n_embd), dtype=np.float32)
+        out = np.empty(self.n_embd, dtype=np.float32)
+        r = self.lib.bert_hip_eval_hidden(self.ctx, _i32p(toks), len(toks), _f32p(hid), _f32p(out))
+        if r != 0:
+            raise RuntimeError(f"bert_hip_eval_hidden failed: {r}")
+        return out, hid
+
+    def profile(self, on: bool) -> None:
+        self.lib.bert_hip_profile_enable(self.ctx, int(on))
+
+    def profile_report(self) -> dict:
+        buf = C.create_string_buffer(1 << 16)
+        self.lib.bert_hip_profile_report(self.ctx, buf, len(buf))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms, flops = line.split()
+            out[name] = {"launches": int(launches), "total_ms": float(ms), "flops_per_launch": float(flops)}
+        return out
+
+    def set_option(self, key: str, value: str) -> None:
+        self.lib.bert_hip_set_option(self.ctx, key.encode(), value.encode())
+
+
+def test_gemm(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias: np.ndarray,
+              resid: Optional[np.ndarray], epilogue: int, impl: int) -> np.ndarray:
+    """A: float16 [M, K]; W_bytes: file-layout bytes of W[N][K]; returns float16 [M, N]."""
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.float16)
+    M, K = A.shape
+    Wb = np.ascontiguousarray(W_bytes)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    out = np.zeros((M, N), dtype=np.float16)
+    rp = None
+    if resid is not None:
+        resid = np.ascontiguousarray(resid, dtype=np.float16)
+        rp = resid.ctypes.data
+    r = L.bert_hip_test_gemm(M, N, K, A.ctypes.data, Wb.ctypes.data, wtype, bias.ctypes.data, rp, epilogue, impl,
+                             out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_gemm failed: {r}")
+    return out
+
+
+def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head: int, impl: int) -> np.ndarray:
+    L = lib()
+    qkv = np.ascontiguousarray(qkv, dtype=np.float16)
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    T = qkv.shape[0]
+    out = np.zeros((T, n_head * d_head), dtype=np.float16)
+    r = L.bert_hip_test_attention(len(cu) - 1, _i32p(cu), n_head, d_head, qkv.ctypes.data, impl, out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_attention failed: {r}")
+    return out

@@ -1,0 +1,86 @@
+/* bert_hip.h — extensions of the MI355X engine beyond the reference's bert.h.
+ *
+ * Plain C ABI (pointers + sizes, no torch / HIP types in the signatures; a stream is passed as a
+ * `void *` that must be a hipStream_t or NULL for the default stream).  None of these exist in
+ * skeskinen/bert.cpp; each entry names the reference code it generalises.
+ */
+#ifndef BERT_HIP_H
+#define BERT_HIP_H
+
+#include "bert.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Tokenizer-only context: header + vocab of a model file, no weights, no GPU needed.
+ * bert_tokenize / bert_vocab_id_to_token / bert_n_max_tokens work; eval prints an error.
+ * (Tokenization is CPU-only in the reference as well: bert.cpp:199-325.)                        */
+BERT_API struct bert_ctx *bert_hip_load_tokenizer(const char *fname);
+
+/* Model facts from the file header (reference bert.cpp:361-367).                                */
+BERT_API int32_t bert_hip_n_layer(struct bert_ctx *ctx);
+BERT_API int32_t bert_hip_n_head(struct bert_ctx *ctx);
+BERT_API int32_t bert_hip_n_intermediate(struct bert_ctx *ctx);
+BERT_API int32_t bert_hip_n_vocab(struct bert_ctx *ctx);
+BERT_API int32_t bert_hip_ftype(struct bert_ctx *ctx);        /* 0 f32, 1 f16, 2 q4_0, 3 q4_1 */
+BERT_API int32_t bert_hip_device(struct bert_ctx *ctx);       /* HIP device ordinal, -1 if none */
+
+/* Packed, variable-length batch evaluation — the engine's native entry point; bert_eval_batch
+ * (reference bert.cpp:730-941) is a wrapper that packs the per-sentence host pointers.
+ *   tokens      [n_tokens_total] ids of all sentences back to back
+ *   cu_seqlens  [n_sentences + 1] exclusive prefix sums of the sentence lengths (cu[0] = 0)
+ *   embeddings  [n_sentences * bert_n_embd] row-major
+ * Returns 0 on success, negative on error (message on stderr, outputs untouched).               */
+BERT_API int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens,
+                                      const int32_t *cu_seqlens, int32_t n_sentences, float *embeddings);
+
+/* Same computation with every buffer already resident in HBM on the context's device; work is
+ * enqueued on `stream` and NOT synchronised (the caller owns the stream).  `max_len` must be >=
+ * the longest sentence (it selects the attention kernel variant); n_tokens_total = cu[n].       */
+BERT_API int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens,
+                                             const int32_t *d_cu_seqlens, int32_t n_sentences,
+                                             int32_t n_tokens_total, int32_t max_len,
+                                             float *d_embeddings, void *stream);
+
+/* Hidden-state tap for parity tests: one sentence, writes hidden[(n_layer+1)][n_tokens][n_embd]
+ * f32 (after the embedding LayerNorm and after every encoder layer, reference bert.cpp:806-901)
+ * and the final embedding.  Either output may be NULL.                                          */
+BERT_API int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id *tokens, int32_t n_tokens,
+                                      float *hidden, float *embedding);
+
+/* Per-kernel timing with HIP events on the launch stream.  While enabled every kernel launch of
+ * the forward pass is bracketed by events (this serialises nothing but adds event overhead, so
+ * never enable it inside a throughput measurement).  bert_hip_profile_report writes one line per
+ * kernel: "<name> <launches> <total_ms> <flops_per_launch_avg>\n" and returns the number of bytes
+ * it needed (excluding NUL); it synchronises the device first and resets the counters.          */
+BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
+BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
+
+/* Engine knobs (also settable through the environment before bert_load_from_file):
+ *   BERT_HIP_DEVICE        device ordinal (default: current device)
+ *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
+ *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
+ *   BERT_HIP_ATTN          "mfma" (default) | "naive"
+ *   BERT_HIP_QUIET         1 = no progress text on stdout during load                            */
+BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
+
+/* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
+ * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
+ * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
+ * 2 bias+residual.  impl: 0 mfma, 1 naive.  Output f16 bits.  Returns 0 on success.            */
+BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
+                                    int32_t wtype, const float *bias, const uint16_t *resid,
+                                    int32_t epilogue, int32_t impl, uint16_t *C);
+
+/* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
+BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
+                                         int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);
+
+BERT_API const char *bert_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* BERT_HIP_H */

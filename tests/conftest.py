@@ -10,6 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("BERT_HIP_QUIET", "1")      # no load-progress text on stdout during tests
 
 
 def pytest_configure(config):
@@ -48,3 +49,28 @@ def sparse_vocab_model(tok_golden, model_dir):
     path = os.path.join(model_dir, "sparse_vocab.bin")
     write_vocab_only_model(path, vocab)
     return path
+
+
+def cosine(a, b):
+    import numpy as np
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+
+
+_MODEL_CACHE = {}
+
+
+@pytest.fixture(scope="session")
+def make_model(model_dir):
+    """make_model(dims, ftype, seed) -> (path, hparams); synthetic seeded weights, cached per session."""
+    from bert_cpp_amd import ggml_file as gf
+
+    def _make(dims, ftype, seed=0):
+        key = (dims, ftype, seed)
+        if key not in _MODEL_CACHE:
+            path = os.path.join(model_dir, f"{dims}_{ftype}_s{seed}.bin")
+            hp = gf.make_synthetic_model(path, dims, ftype, seed=seed)
+            _MODEL_CACHE[key] = (path, hp)
+        return _MODEL_CACHE[key]
+
+    return _make
