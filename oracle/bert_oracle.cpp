@@ -268,37 +268,60 @@ struct Tables {            // table_exp_f16 / table_gelu_f16 semantics, built la
 };
 const Tables &tables() { static const Tables t; return t; }
 
+// ---- SIMD helpers (GCC vector extensions: lowered to AVX-512 / AVX2 / NEON by -march=native) ----
+typedef float v16f __attribute__((vector_size(64)));
+typedef int v16i __attribute__((vector_size(64)));
+typedef short v32s __attribute__((vector_size(64)));
+typedef short v16s __attribute__((vector_size(32)));
+typedef signed char v32c __attribute__((vector_size(32)));
+
+inline float hsum(v16f v) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += v[i];
+    return s;
+}
+
+// 4 tokens x 4 outputs register block of f32 dot products (f32 accumulate, like ggml_vec_dot_f32 /
+// the F16C path of ggml_vec_dot_f16: products and sums in f32 SIMD lanes, reduced at the end).
+void dot_block_f32(const float *x, int ldx, const float *w, int ldw, int K, int nt, int nn, float out[4][4]) {
+    v16f acc[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] = (v16f){0};
+    int k = 0;
+    for (; k + 16 <= K; k += 16) {
+        v16f xv[4], wv[4];
+        for (int a = 0; a < 4; ++a) memcpy(&xv[a], x + (size_t)(a < nt ? a : 0) * ldx + k, 64);
+        for (int b = 0; b < 4; ++b) memcpy(&wv[b], w + (size_t)(b < nn ? b : 0) * ldw + k, 64);
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) acc[a][b] += xv[a] * wv[b];
+    }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+        float s = hsum(acc[a][b]);
+        if (a < nt && b < nn) for (int kk = k; kk < K; ++kk) s += x[(size_t)a * ldx + kk] * w[(size_t)b * ldw + kk];
+        out[a][b] = s;
+    }
+}
+
 // y[t][n] = sum_k W[n][k] * x[t][k] + b[n]   (ggml_mul_mat(W, X) + repeat(b)), X is [T][K] f32
 void linear(const Matrix &W, const std::vector<float> &bias, const float *X, int T, float *Y, int mode) {
     const int K = W.cols, N = W.rows;
-    if (mode == 1 || W.type == T_F32) {
-#pragma omp parallel for schedule(static)
-        for (int t = 0; t < T; ++t) {
-            const float *x = X + (size_t)t * K;
-            for (int n = 0; n < N; ++n) {
-                const float *w = W.f.data() + (size_t)n * K;
-                float s = 0.f;
-#pragma omp simd reduction(+ : s)
-                for (int k = 0; k < K; ++k) s += w[k] * x[k];
-                Y[(size_t)t * N + n] = s + bias[n];
-            }
+    if (mode == 1 || W.type == T_F32 || W.type == T_F16) {
+        // f16 weights in ggml mode: src1 is converted to f16 in the work buffer, f32 accumulate
+        std::vector<float> xr;
+        const float *Xs = X;
+        if (mode == 0 && W.type == T_F16) {
+            xr.resize((size_t)T * K);
+            for (size_t i = 0; i < xr.size(); ++i) xr[i] = round_f16(X[i]);
+            Xs = xr.data();
         }
-        return;
-    }
-    if (W.type == T_F16) {      // src1 converted to f16 in the work buffer, f32 accumulate
-        std::vector<float> xr((size_t)T * K);
-        for (size_t i = 0; i < xr.size(); ++i) xr[i] = round_f16(X[i]);
-#pragma omp parallel for schedule(static)
-        for (int t = 0; t < T; ++t) {
-            const float *x = xr.data() + (size_t)t * K;
-            for (int n = 0; n < N; ++n) {
-                const float *w = W.f.data() + (size_t)n * K;
-                float s = 0.f;
-#pragma omp simd reduction(+ : s)
-                for (int k = 0; k < K; ++k) s += w[k] * x[k];
-                Y[(size_t)t * N + n] = s + bias[n];
+        const int tb = (T + 3) / 4, nb = (N + 3) / 4;
+#pragma omp parallel for schedule(static) collapse(2)
+        for (int ti = 0; ti < tb; ++ti)
+            for (int ni = 0; ni < nb; ++ni) {
+                const int t0 = ti * 4, n0 = ni * 4, nt = std::min(4, T - t0), nn = std::min(4, N - n0);
+                float o[4][4];
+                dot_block_f32(Xs + (size_t)t0 * K, K, W.f.data() + (size_t)n0 * K, K, K, nt, nn, o);
+                for (int a = 0; a < nt; ++a)
+                    for (int b = 0; b < nn; ++b) Y[(size_t)(t0 + a) * N + n0 + b] = o[a][b] + bias[n0 + b];
             }
-        }
         return;
     }
     // q4_0 x q8_0  /  q4_1 x q8_1
@@ -321,23 +344,34 @@ void linear(const Matrix &W, const std::vector<float> &bias, const float *X, int
             if (W.type == T_Q4_0) xd[(size_t)t * nb + b] = round_f16(d);       // block_q8_0.d is fp16
             else { xd[(size_t)t * nb + b] = d; xs[(size_t)t * nb + b] = d * sum; }  // block_q8_1 {float d, s}
         }
-#pragma omp parallel for schedule(static)
-    for (int t = 0; t < T; ++t) {
-        const int8_t *x = xq.data() + (size_t)t * K;
+    // integer block dot: products of (q4 [-8,15]) x (q8 [-127,127]) in int16 lanes, pairs summed in
+    // int32, scaled by d4*d8 per block and accumulated in f32 SIMD lanes — the shape of ggml's AVX2
+    // ggml_vec_dot_q4_0_q8_0 (integer partial sums -> float -> fmadd with the block scale).
+    const int tbk = (T + 3) / 4;
+#pragma omp parallel for schedule(static) collapse(2)
+    for (int ti = 0; ti < tbk; ++ti)
         for (int n = 0; n < N; ++n) {
+            const int t0 = ti * 4, nt = std::min(4, T - t0);
             const int8_t *w = W.q.data() + (size_t)n * K;
-            float sumf = 0.f;
+            v16f acc[4] = {(v16f){0}, (v16f){0}, (v16f){0}, (v16f){0}};
+            float macc[4] = {0.f, 0.f, 0.f, 0.f};
             for (int b = 0; b < nb; ++b) {
-                int sumi = 0;
-#pragma omp simd reduction(+ : sumi)
-                for (int j = 0; j < QK; ++j) sumi += (int)w[b * QK + j] * (int)x[b * QK + j];
+                v32c wc; memcpy(&wc, w + b * QK, 32);
+                const v32s w16 = __builtin_convertvector(wc, v32s);
                 const float d4 = W.d[(size_t)n * nb + b];
-                if (W.type == T_Q4_0) sumf += sumi * d4 * xd[(size_t)t * nb + b];
-                else sumf += (d4 * xd[(size_t)t * nb + b]) * sumi + W.m[(size_t)n * nb + b] * xs[(size_t)t * nb + b];
+                for (int a = 0; a < nt; ++a) {
+                    const size_t t = (size_t)(t0 + a);
+                    v32c xc; memcpy(&xc, xq.data() + t * K + b * QK, 32);
+                    const v32s p = w16 * __builtin_convertvector(xc, v32s);
+                    v16s lo, hi; memcpy(&lo, &p, 32); memcpy(&hi, (const char *)&p + 32, 32);
+                    const v16i s32 = __builtin_convertvector(lo, v16i) + __builtin_convertvector(hi, v16i);
+                    const float sc = d4 * xd[t * nb + b];
+                    acc[a] += __builtin_convertvector(s32, v16f) * sc;
+                    if (W.type == T_Q4_1) macc[a] += W.m[(size_t)n * nb + b] * xs[t * nb + b];
+                }
             }
-            Y[(size_t)t * N + n] = sumf + bias[n];
+            for (int a = 0; a < nt; ++a) Y[(size_t)(t0 + a) * N + n] = hsum(acc[a]) + macc[a] + bias[n];
         }
-    }
 }
 
 // ggml_norm (eps = 1e-5, double accumulators) followed by gamma * x + beta   (bert.cpp:806-814)

@@ -24,6 +24,29 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def usable_cores() -> int:
+    """CPU cores this process may actually use: min(affinity, cgroup quota).  The GPU box reports
+    256 logical CPUs; spinning up one OpenMP thread per logical CPU for 128-row loops is slower
+    than a handful of threads, so callers cap this further (default_threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def default_threads() -> int:
+    """Thread count the oracle uses unless told otherwise (intra-op, like ggml's n_threads)."""
+    env = os.environ.get("ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    return min(usable_cores(), 16)
+
+
 _lib = None
 
 
@@ -31,6 +54,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # before libgomp initialises
+        os.environ.setdefault("OMP_PROC_BIND", "false")
         L = C.CDLL(_LIB_PATH)
         L.oracle_load.restype = C.c_void_p
         L.oracle_load.argtypes = [C.c_char_p, C.c_int]
@@ -99,6 +124,8 @@ class Oracle:
         if want_hidden:
             hid = np.empty((self.n_layer + 1, len(toks), self.n_embd), dtype=np.float32)
             hp = hid.ctypes.data_as(C.POINTER(C.c_float))
+        if n_threads <= 0:
+            n_threads = default_threads()
         r = self._L.oracle_eval(self._h, mode, n_threads, toks.ctypes.data_as(C.POINTER(C.c_int32)), len(toks),
                                 out.ctypes.data_as(C.POINTER(C.c_float)), hp)
         if r != 0:
