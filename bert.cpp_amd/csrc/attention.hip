@@ -40,7 +40,11 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,
                                                              half_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x / n_head, h = blockIdx.x % n_head;
+    // XCD-contiguous logical order (see gemm.hip xcd_remap): the heads of one sentence share the
+    // 128-byte lines of its Q|K|V rows, so they should hit the same XCD's L2.
+    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
+    const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int b = lb / n_head, h = lb % n_head;
     const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
     if (n <= 0) return;
     const int H = n_head * D, ld = 3 * H;
@@ -113,13 +117,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float m_new = fmaxf(m_run, mx);           // finite: every chunk has >= 1 real key
-            const float alpha = exp2f(m_run - m_new);        // 0 on the first chunk
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
             float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f(s[kt][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
                     s[kt][r] = pv;
                     psum += pv;
                 }

@@ -60,8 +60,20 @@ __device__ __forceinline__ void dma_tile(const half_t *src, int ld, char *tile, 
 
 __device__ __forceinline__ float gelu_tanh(float x) {
     // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  u = sqrt(2/pi) x (1 + 0.044715 x^2)
-    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    return x / (1.0f + __expf(-2.0f * u));
+    // exp(-2u) = exp2(x * (c1 + c2 x^2)); one v_exp_f32 + one v_rcp_f32 per element.
+    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
+    const float c2 = c1 * 0.044715f;
+    const float t = x * __builtin_fmaf(x * x, c2, c1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+// L2).  Remap so that every XCD walks a CONTIGUOUS range of logical tiles: all feature tiles of one
+// token tile then run back to back on one XCD and the activation tile is fetched from HBM once
+// instead of once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 // 4 bytes each holding a nibble value 0..15  ->  two f16x2 = (1024+n0, 1024+n1), (1024+n2, 1024+n3)
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = blockIdx.x % p.n_tiles_n, mt = blockIdx.x / p.n_tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = lb % p.n_tiles_n, mt = lb / p.n_tiles_n;
     const int m0 = mt * GEMM_BM, n0 = nt * GEMM_BN;
     const int K = p.K, nk = K / GEMM_BK;
     const int wf = wave & 1, wt = wave >> 1;          // feature half / token half of the tile
@@ -184,34 +197,50 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane owns token column (l31) and 4-feature runs
+    // ---- epilogue.  Accumulator layout: lane owns token column l31 and 4-feature register runs.
+    // Stage the 128x128 f32 tile in LDS (16-B chunk index XOR (token & 31): conflict-free both ways),
+    // then every wave-instruction writes two full 256-B output rows: 32 lanes x 4 features each.
+    // (The last reduction tile ended with a barrier, so the staging buffers are free.)
+    float *Cs = (float *)smem;                 // [128 tokens][32 chunks of 4 floats]
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = n0 + wf * 64 + i * 32 + 8 * g + 4 * hi;
-            if (f0 >= p.N) continue;
-            const f32x4 bv = *(const f32x4 *)(p.bias + f0);
+        for (int j = 0; j < 2; ++j) {
+            const int tok = wt * 64 + j * 32 + l31;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const size_t t = (size_t)m0 + wt * 64 + j * 32 + l31;
-                float v[4];
+            for (int g = 0; g < 4; ++g) {
+                const int chunk = wf * 16 + i * 8 + g * 2 + hi;
+                f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-                if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (EPI == EPI_BIAS_RESID) {
-                    const f16x4 rv = *(const f16x4 *)(p.resid + t * p.N + f0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                }
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *(f16x4 *)(p.C + t * p.N + f0) = o;
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                *(f32x4 *)(Cs + tok * 128 + ((chunk ^ (tok & 31)) << 2)) = v;
             }
+        }
+    __syncthreads();
+    const int chunk = tid & 31;
+    const int f0 = n0 + chunk * 4;
+    if (f0 < p.N) {
+        const f32x4 bv = *(const f32x4 *)(p.bias + f0);
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int tok = s * 8 + (tid >> 5);
+            f32x4 v = *(const f32x4 *)(Cs + tok * 128 + ((chunk ^ (tok & 31)) << 2));
+            const size_t off = ((size_t)m0 + tok) * p.N + f0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += bv[e];
+            if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
+            }
+            if (EPI == EPI_BIAS_RESID) {
+                const f16x4 rv = *(const f16x4 *)(p.resid + off);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+            }
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+            *(f16x4 *)(p.C + off) = o;
         }
     }
 }

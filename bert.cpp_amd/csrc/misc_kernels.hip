@@ -29,8 +29,24 @@ __device__ __forceinline__ float table_elem(const void *tab, int type, int H, in
     return (float)q * d + m;
 }
 
+// Two adjacent elements (e, e+1; e even) of row r of a table, dequantised to f32.
+__device__ __forceinline__ void table_pair(const void *tab, int type, int H, int r, int e, float &a, float &b) {
+    if (type == 0) {
+        const float2 v = *(const float2 *)((const float *)tab + (size_t)r * H + e);
+        a = v.x; b = v.y;
+    } else if (type == 1) {
+        const f16x2 v = *(const f16x2 *)((const half_t *)tab + (size_t)r * H + e);
+        a = (float)v[0]; b = (float)v[1];
+    } else {
+        a = table_elem(tab, type, H, r, e);
+        b = table_elem(tab, type, H, r, e + 1);
+    }
+}
+
 // reference bert.cpp:796-814: inpL = word[ids]; inpL = type[0] + inpL; inpL = pos[0..N-1] + inpL;
-// LayerNorm (ggml_norm eps 1e-5) then gamma * x + beta.
+// LayerNorm (ggml_norm eps 1e-5) then gamma * x + beta.  One wave per token, one pass: the row is
+// held in registers as NJ element pairs per lane (H <= 128 * NJ, H even).
+template <int NJ>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const void *type, const void *pos,
                                                        int table_type, const float *gamma, const float *beta,
                                                        const int32_t *tokens, const int32_t *cu_seqlens,
@@ -47,28 +63,42 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const v
     int id = tokens[t];
     id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);   // ids are validated on the host API; clamp for safety
 
+    float v[NJ][2];
     float sum = 0.f;
-    for (int e = lane; e < H; e += 64) {
-        float v = table_elem(word, table_type, H, id, e);
-        v = table_elem(type, table_type, H, 0, e) + v;
-        v = table_elem(pos, table_type, H, p, e) + v;
-        sum += v;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        v[j][0] = v[j][1] = 0.f;
+        if (e < H) {
+            float w0, w1, t0, t1, p0, p1;
+            table_pair(word, table_type, H, id, e, w0, w1);
+            table_pair(type, table_type, H, 0, e, t0, t1);
+            table_pair(pos, table_type, H, p, e, p0, p1);
+            v[j][0] = p0 + (t0 + w0);
+            v[j][1] = p1 + (t1 + w1);
+            sum += v[j][0] + v[j][1];
+        }
     }
     const float mean = wave_sum(sum) / H;
     float sq = 0.f;
-    for (int e = lane; e < H; e += 64) {
-        float v = table_elem(word, table_type, H, id, e);
-        v = table_elem(type, table_type, H, 0, e) + v;
-        v = table_elem(pos, table_type, H, p, e) + v;
-        v -= mean;
-        sq += v * v;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        if (e < H) {
+            v[j][0] -= mean; v[j][1] -= mean;
+            sq += v[j][0] * v[j][0] + v[j][1] * v[j][1];
+        }
     }
     const float rstd = 1.0f / sqrtf(wave_sum(sq) / H + 1e-5f);
-    for (int e = lane; e < H; e += 64) {
-        float v = table_elem(word, table_type, H, id, e);
-        v = table_elem(type, table_type, H, 0, e) + v;
-        v = table_elem(pos, table_type, H, p, e) + v;
-        out[(size_t)t * H + e] = (_Float16)(gamma[e] * ((v - mean) * rstd) + beta[e]);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int e = 2 * lane + 128 * j;
+        if (e < H) {
+            f16x2 o;
+            o[0] = (_Float16)(gamma[e] * (v[j][0] * rstd) + beta[e]);
+            o[1] = (_Float16)(gamma[e + 1] * (v[j][1] * rstd) + beta[e + 1]);
+            *(f16x2 *)(out + (size_t)t * H + e) = o;
+        }
     }
 }
 
@@ -76,8 +106,12 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
                      const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
                      int H, int n_vocab, half_t *out, hipStream_t stream) {
     if (T <= 0) return;
-    hipLaunchKernelGGL(embed_ln_kernel, dim3((T + 3) / 4), dim3(256), 0, stream, word, type, pos, table_type, gamma,
-                       beta, tokens, cu_seqlens, n_sentences, T, H, n_vocab, out);
+    const dim3 grid((T + 3) / 4), block(256);
+    const int nj = (H + 127) / 128;
+#define EMB(NJ) hipLaunchKernelGGL(embed_ln_kernel<NJ>, grid, block, 0, stream, word, type, pos, table_type, gamma, \
+                                   beta, tokens, cu_seqlens, n_sentences, T, H, n_vocab, out)
+    if (nj <= 1) EMB(1); else if (nj <= 3) EMB(3); else if (nj <= 6) EMB(6); else if (nj <= 8) EMB(8); else EMB(32);
+#undef EMB
 }
 
 // reference bert.cpp:868-874 / :894-900 (ggml_norm + gamma/beta), in place on f16 rows.
@@ -133,31 +167,43 @@ void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, i
 }
 
 // reference bert.cpp:904-913: mean over all N tokens (mat-vec with a 1/N vector), then y / ||y||_2.
+// One workgroup per sentence; wave w sums tokens w, w+4, ... over coalesced half2 row reads, the
+// four partial rows are combined through LDS.
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, const int32_t *cu_seqlens, int H,
                                                              float *out) {
-    __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ float part[];          // [4][H] partial sums, then red[4]
+    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
     const float invn = 1.0f / (float)n;
+    for (int e = 2 * lane; e < H; e += 128) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int t = wave; t < n; t += 4) {
+            const f16x2 v = *(const f16x2 *)(x + (size_t)(tok0 + t) * H + e);
+            a0 += (float)v[0] * invn; a1 += (float)v[1] * invn;
+        }
+        part[wave * H + e] = a0; part[wave * H + e + 1] = a1;
+    }
+    __syncthreads();
     float sq = 0.f;
     for (int e = tid; e < H; e += 256) {
-        float a = 0.f;
-        for (int t = 0; t < n; ++t) a += (float)x[(size_t)(tok0 + t) * H + e] * invn;
-        out[(size_t)b * H + e] = a;
+        const float a = (part[e] + part[H + e]) + (part[2 * H + e] + part[3 * H + e]);
+        part[e] = a;
         sq += a * a;
     }
     sq = wave_sum(sq);
-    if ((tid & 63) == 0) red[tid >> 6] = sq;
     __syncthreads();
-    const float len2 = red[0] + red[1] + red[2] + red[3];
-    const float scale = 1.0f / sqrtf(len2);
-    for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] *= scale;
+    float *red = part + 4 * H;
+    if (lane == 0) red[wave] = sq;
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] = part[e] * scale;
 }
 
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
                            hipStream_t stream) {
     if (n_sentences <= 0) return;
-    hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_sentences), dim3(256), 0, stream, x, cu_seqlens, H, out);
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_sentences), dim3(256), (4 * H + 4) * sizeof(float), stream, x,
+                       cu_seqlens, H, out);
 }
 
 __global__ void f16_to_f32_kernel(const half_t *src, float *dst, size_t n) {
