@@ -170,6 +170,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     }
     if (const char *g = getenv("BERT_HIP_GEMM")) e->gemm_naive_ = strcmp(g, "naive") == 0;
     if (const char *a = getenv("BERT_HIP_ATTN")) e->attn_naive_ = strcmp(a, "naive") == 0;
+    if (const char *f = getenv("BERT_HIP_FFN")) e->ffn_fused_ = strcmp(f, "unfused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -222,6 +223,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     if (key == "gemm") {
         gemm_naive_ = value == "naive";
     } else if (key == "attn") attn_naive_ = value == "naive";
+    else if (key == "ffn") ffn_fused_ = value != "unfused";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -310,9 +312,16 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         });
         gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
         timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
-        gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
-        gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
-        timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+        if (ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w)) {
+            timed("ffn_fused", 4.0 * Td * H * I, s, [&] {
+                launch_ffn_fused(L.ffi.w, L.ffo.w, y, L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(),
+                                 L.ln_out_b.as<float>(), x, t_pad, s);
+            });
+        } else {
+            gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
+            gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
+            timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+        }
         tap(il + 1);
     }
     timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, d_out, s); });

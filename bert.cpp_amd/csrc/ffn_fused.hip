@@ -1,0 +1,293 @@
+// ffn_fused.hip — the whole feed-forward block of an encoder layer in ONE kernel (gfx950):
+//     x_out = LayerNorm( gelu(y W1^T + b1) W2^T + b2 + y ) * gamma + beta
+//
+// Replaces ggml_mul_mat(ff_i_w) + bias + ggml_gelu + ggml_mul_mat(ff_o_w) + bias + residual add +
+// ggml_norm + gamma/beta (reference bert.cpp:878-901) — 63 % of the forward pass's FLOPs.  The
+// [tokens, n_intermediate] activation never exists in HBM: it is produced and consumed in LDS in
+// 128-feature chunks, and the LayerNorm is done on the accumulators.
+//
+// One workgroup = 128 tokens, 8 waves (2 token halves x 4 feature quarters of a 128-wide tile).
+// For every 128-wide chunk c of the intermediate dimension:
+//   U phase  accU[128 tok x 128]  = y_tile * W1[c]^T         (K = H, streamed in 64-deep tiles)
+//            hc = f16(gelu(accU + b1[c]))  -> LDS (swizzled [128][128])
+//   D phase  acc2[128 tok x H]   += hc * W2[:, c]^T          (K = 128, H/128 feature thirds)
+// All operands of both phases arrive as one uniform stream of 32-KiB ring slots (U: y k-tile + W1
+// k-tile, D: W2 tile) written by global_load_lds_dwordx4 two tiles ahead of their use and retired
+// with a counted s_waitcnt vmcnt(N) + one s_barrier per tile, so the matrix pipe never drains
+// between the 12 x (H/64 + 2 H/128) tiles of a workgroup.  MFMA operand roles are as in gemm.hip
+// (weights = A operand, activations = B operand: a lane's accumulator column is one token), which
+// makes the GELU epilogue, the residual add and the LayerNorm statistics per-lane-column work.
+#include "kernels.h"
+
+namespace bert_hip {
+
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define AS_GLOBAL(p) ((const __attribute__((address_space(1))) void *)(p))
+#define AS_LDS(p) ((__attribute__((address_space(3))) void *)(p))
+
+struct FfnArgs {
+    const half_t *y;       // [T_pad][H]   LayerNorm'ed attention output (input and residual)
+    const half_t *w1;      // [I_pad][H]   f16
+    const half_t *w2;      // [H_pad][I]   f16
+    const float *b1, *b2, *gamma, *beta;
+    half_t *out;           // [T_pad][H]
+    int I;
+};
+
+constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
+constexpr int FF_RING = 3 * FF_SLOT;
+constexpr int FF_HC = FF_RING;                 // [128][128] f16 = 32 KiB
+constexpr int FF_CONST = FF_HC + 32768;        // b1[I], then b2, gamma, beta [H], then LN scratch
+
+__device__ __forceinline__ int off64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int off_hc(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
+
+// 128 rows x 64 halfs (128-B rows) -> 16 KiB LDS tile; this wave moves rows [wave*16, wave*16+16)
+__device__ __forceinline__ void dma_tile8(const half_t *src, int ld, char *tile, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int g = wave * 2 + i;
+        const int r = g * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + (size_t)r * ld + c * 8), AS_LDS(tile + g * 1024), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
+    const float c2 = c1 * 0.044715f;
+    const float t = x * __builtin_fmaf(x * x, c2, c1);
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+}
+
+template <int G>
+__device__ __forceinline__ void wait_vm_barrier() {
+    // retire everything but the newest G DMA pieces of this wave, make own LDS writes visible, sync
+    if (G == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 128 * NT, KU = H / 64, TPC = KU + 2 * NT;
+    const int I = a.I, NC = I / 128, NTILES = NC * TPC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wt = wave >> 2, wq = wave & 3;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+
+    char *ring = smem;
+    char *hc = smem + FF_HC;
+    float *cb1 = (float *)(smem + FF_CONST);
+    float *cb2 = cb1 + I, *cg = cb2 + H, *cbeta = cg + H;
+    float *red = cbeta + H;                                   // [4 quarters][128 tokens]
+
+    const half_t *ybase = a.y + (size_t)m0 * H;
+
+    // tile t -> ring slot t % 3
+    auto issue = [&](int t) {
+        const int c = t / TPC, p = t - c * TPC;
+        char *slot = ring + (t % 3) * FF_SLOT;
+        if (p < KU) {
+            dma_tile8(ybase + p * 64, H, slot, wave, lane);
+            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, H, slot + 16384, wave, lane);
+        } else {
+            const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
+            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, I, slot, wave, lane);
+        }
+    };
+
+    // ---- prologue: constants into LDS, first two tiles in flight
+    for (int i = tid; i < I; i += 512) cb1[i] = a.b1[i];
+    for (int i = tid; i < H; i += 512) { cb2[i] = a.b2[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
+    issue(0);
+    issue(1);
+
+    f32x16 acc2[NT][2], accU[2];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[n][j][r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
+
+    for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int p = 0; p < TPC; ++p) {
+            const int t = c * TPC + p;
+            // tile t landed for every wave?  (tile t+1 may stay in flight: 4 pieces if U, 2 if D)
+            if (t + 1 < NTILES) {
+                if (((p + 1) % TPC) < KU) wait_vm_barrier<4>(); else wait_vm_barrier<2>();
+            } else {
+                wait_vm_barrier<0>();
+            }
+            if (t + 2 < NTILES) issue(t + 2);       // its slot was read in interval t-1: free after the barrier
+            const char *slot = ring + (t % 3) * FF_SLOT;
+            if (p < KU) {
+                // ---- U: accU += W1tile (features) x ytile (tokens)
+                const char *yT = slot, *wT = slot + 16384;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = kk * 2 + hi;
+                    const f16x8 wf = *(const f16x8 *)(wT + off64(wq * 32 + l31, ch));
+                    const f16x8 a0 = *(const f16x8 *)(yT + off64(wt * 64 + l31, ch));
+                    const f16x8 a1 = *(const f16x8 *)(yT + off64(wt * 64 + 32 + l31, ch));
+                    accU[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a0, accU[0], 0, 0, 0);
+                    accU[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a1, accU[1], 0, 0, 0);
+                }
+                if (p == KU - 1) {
+                    // ---- chunk epilogue: bias + GELU, f16, into hc[token][feature] (read by the D tiles
+                    // after the next barrier; last read of the previous chunk's hc was >= KU barriers ago)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int fl = wq * 32 + 8 * g + 4 * hi;
+                        const f32x4 bv = *(const f32x4 *)(cb1 + c * 128 + fl);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int tok = wt * 64 + j * 32 + l31;
+                            f16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (_Float16)gelu_fast(accU[j][4 * g + e] + bv[e]);
+                            *(f16x4 *)(hc + off_hc(tok, fl >> 3) + (fl & 4) * 2) = o;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
+                }
+            } else {
+                // ---- D: acc2[n3] += W2tile (features) x hc (tokens), k-half k2 of the chunk
+                constexpr int dummy = 0; (void)dummy;
+                const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = kk * 2 + hi;
+                    const f16x8 wf = *(const f16x8 *)(slot + off64(wq * 32 + l31, ch));
+                    const f16x8 a0 = *(const f16x8 *)(hc + off_hc(wt * 64 + l31, k2 * 8 + ch));
+                    const f16x8 a1 = *(const f16x8 *)(hc + off_hc(wt * 64 + 32 + l31, k2 * 8 + ch));
+                    acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a0, acc2[n3][0], 0, 0, 0);
+                    acc2[n3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a1, acc2[n3][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- final epilogue: + b2 + residual, LayerNorm over H per token, gamma/beta, store.
+    // lane owns tokens tok_j = wt*64 + j*32 + l31 and features f = n*128 + wq*32 + 8g + 4hi + e
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f0 = n * 128 + wq * 32 + 8 * g + 4 * hi;
+            const f32x4 bv = *(const f32x4 *)(cb2 + f0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tok = wt * 64 + j * 32 + l31;
+                const f16x4 rv = *(const f16x4 *)(ybase + (size_t)tok * H + f0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc2[n][j][4 * g + e] + bv[e] + (float)rv[e];
+                    acc2[n][j][4 * g + e] = v;
+                    sum[j] += v;
+                }
+            }
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves are past their last ring / hc read
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sum[j] += __shfl_xor(sum[j], 32);
+        if (hi == 0) red[wq * 128 + wt * 64 + j * 32 + l31] = sum[j];
+    }
+    __syncthreads();
+    float mean[2], sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tok = wt * 64 + j * 32 + l31;
+        mean[j] = ((red[tok] + red[128 + tok]) + (red[256 + tok] + red[384 + tok])) * (1.0f / H);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc2[n][j][r] - mean[j];
+                acc2[n][j][r] = d;
+                sq[j] += d * d;
+            }
+    __syncthreads();                                           // everyone has read the sums
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        sq[j] += __shfl_xor(sq[j], 32);
+        if (hi == 0) red[wq * 128 + wt * 64 + j * 32 + l31] = sq[j];
+    }
+    __syncthreads();
+    half_t *Cs = (half_t *)ring;                               // [128 tokens][H] f16, 16-B chunk ^ (tok & 15)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int tok = wt * 64 + j * 32 + l31;
+        const float var = ((red[tok] + red[128 + tok]) + (red[256 + tok] + red[384 + tok])) * (1.0f / H);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = n * 128 + wq * 32 + 8 * g + 4 * hi;
+                const f32x4 gv = *(const f32x4 *)(cg + f0), bv = *(const f32x4 *)(cbeta + f0);
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)(gv[e] * (acc2[n][j][4 * g + e] * rstd) + bv[e]);
+                const int chunk = f0 >> 3;
+                *(f16x4 *)(Cs + (size_t)tok * H + (((chunk & ~15) | ((chunk ^ tok) & 15)) << 3) + (f0 & 4)) = o;
+            }
+    }
+    __syncthreads();
+    constexpr int CPR = H / 8;                                 // 16-byte chunks per row
+    for (int idx = tid; idx < 128 * CPR; idx += 512) {
+        const int tok = idx / CPR, chunk = idx - tok * CPR;
+        const uint4 v = *(const uint4 *)(Cs + (size_t)tok * H + (((chunk & ~15) | ((chunk ^ tok) & 15)) << 3));
+        *(uint4 *)(a.out + ((size_t)m0 + tok) * H + chunk * 8) = v;
+    }
+}
+
+bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
+    const int H = W1.K, I = W1.N;
+    return W1.type == GW_F16 && W2.type == GW_F16 && W2.N == H && W2.K == I && H % 128 == 0 && H <= 384 &&
+           I % 128 == 0 && I <= 6144;
+}
+
+void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
+                      const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream) {
+    FfnArgs a;
+    a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.I = W1.N;
+    const int H = W1.K;
+    const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
+    const int grid = M_pad / 128;
+    static bool configured[4] = {false, false, false, false};
+    auto cfg = [&](const void *fn, int nt) {
+        if (!configured[nt]) {
+            hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured[nt] = true;
+        }
+    };
+    switch (H / 128) {
+        case 1: cfg((const void *)ffn_fused_kernel<1>, 1); hipLaunchKernelGGL(ffn_fused_kernel<1>, dim3(grid), dim3(512), lds, stream, a); break;
+        case 2: cfg((const void *)ffn_fused_kernel<2>, 2); hipLaunchKernelGGL(ffn_fused_kernel<2>, dim3(grid), dim3(512), lds, stream, a); break;
+        default: cfg((const void *)ffn_fused_kernel<3>, 3); hipLaunchKernelGGL(ffn_fused_kernel<3>, dim3(grid), dim3(512), lds, stream, a); break;
+    }
+}
+
+}  // namespace bert_hip

@@ -37,6 +37,10 @@ struct GemmWeight {
 // lda = K, ldc = ldr = N.  MFMA path requires K % 64 == 0.
 void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
                       int M_pad, int epilogue, hipStream_t stream);
+// Whole FFN block + residual + LayerNorm in one kernel (ffn_fused.hip); y and out must differ.
+bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2);
+void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
+                      const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream);
 // Generic fallback (any K, N); needs W.naive16.
 void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
                        int M, int epilogue, hipStream_t stream);

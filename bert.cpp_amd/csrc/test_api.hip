@@ -48,6 +48,40 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     return 0;
 }
 
+int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2, int32_t wtype,
+                          const float *b1, const float *b2, const float *gamma, const float *beta, int32_t fused,
+                          uint16_t *out) {
+    std::string err;
+    HostTensor t1, t2;
+    t1.type = wtype; t1.n_dims = 2; t1.ne0 = H; t1.ne1 = I; t1.data = (const uint8_t *)W1; t1.nbytes = wtype_row_bytes(wtype, H) * (size_t)I;
+    t2.type = wtype; t2.n_dims = 2; t2.ne0 = I; t2.ne1 = H; t2.data = (const uint8_t *)W2; t2.nbytes = wtype_row_bytes(wtype, I) * (size_t)H;
+    GemmWeightStore w1, w2;
+    if (!w1.build({&t1}, false, err) || !w2.build({&t2}, false, err)) { fprintf(stderr, "bert_hip_test_ffn: %s\n", err.c_str()); return -1; }
+    if (!w1.mfma_ok || !w2.mfma_ok) return -2;
+    if (fused && !ffn_fused_supported(w1.w, w2.w)) return -2;
+    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    DevBuf dy, dff, dout, db1, db2, dg, dbt;
+    if (!dy.alloc((size_t)M_pad * H * 2, err) || !dff.alloc((size_t)M_pad * I * 2, err) || !dout.alloc((size_t)M_pad * H * 2, err) ||
+        !db1.upload(b1, (size_t)I * 4, err) || !db2.upload(b2, (size_t)H * 4, err) || !dg.upload(gamma, (size_t)H * 4, err) ||
+        !dbt.upload(beta, (size_t)H * 4, err)) {
+        fprintf(stderr, "bert_hip_test_ffn: %s\n", err.c_str());
+        return -1;
+    }
+    CK(hipMemcpy(dy.p, y, (size_t)M * H * 2, hipMemcpyHostToDevice));
+    if (fused) {
+        launch_ffn_fused(w1.w, w2.w, dy.as<half_t>(), db1.as<float>(), db2.as<float>(), dg.as<float>(), dbt.as<float>(),
+                         dout.as<half_t>(), M_pad, nullptr);
+    } else {
+        launch_gemm_mfma(w1.w, dy.as<half_t>(), db1.as<float>(), nullptr, dff.as<half_t>(), M_pad, EPI_BIAS_GELU, nullptr);
+        launch_gemm_mfma(w2.w, dff.as<half_t>(), db2.as<float>(), dy.as<half_t>(), dout.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
+        launch_layernorm(dout.as<half_t>(), dg.as<float>(), dbt.as<float>(), M, H, nullptr);
+    }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
                                 const uint16_t *qkv, int32_t impl, uint16_t *out) {
     std::string err;

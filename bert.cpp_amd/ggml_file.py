@@ -121,6 +121,7 @@ MODEL_DIMS: Dict[str, BertHParams] = {
     "mpnet-dims": BertHParams(30527, 514, 768, 3072, 12, 12),     # BERT-arch at mpnet-base dims
     "tiny": BertHParams(256, 64, 64, 128, 2, 2),                  # unit-test size (d_head 32)
     "tiny-d64": BertHParams(300, 96, 128, 256, 2, 2),             # d_head = 64 variant
+    "tiny-h128": BertHParams(256, 64, 128, 256, 4, 2),            # H % 128 == 0: fused-FFN kernel path
     "tiny-d16": BertHParams(256, 64, 64, 192, 4, 1),              # d_head = 16 (generic-kernel path)
 }
 

@@ -24,7 +24,7 @@ BERT_HIP_H_SYMBOLS = [
     "bert_hip_load_tokenizer", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
-    "bert_hip_test_attention", "bert_hip_version",
+    "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_version",
 ]
 
 
@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
     L.bert_hip_set_option.restype = None; L.bert_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
+    L.bert_hip_test_ffn.restype = i32
+    L.bert_hip_test_ffn.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.bert_hip_test_attention.restype = i32
     L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
     L.bert_hip_version.restype = C.c_char_p
@@ -226,4 +228,20 @@ def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head:
     r = L.bert_hip_test_attention(len(cu) - 1, _i32p(cu), n_head, d_head, qkv.ctypes.data, impl, out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_attention failed: {r}")
+    return out
+
+
+def test_ffn(y: np.ndarray, W1_bytes: np.ndarray, W2_bytes: np.ndarray, wtype: int, I: int, b1, b2, gamma, beta,
+             fused: bool) -> np.ndarray:
+    L = lib()
+    y = np.ascontiguousarray(y, dtype=np.float16)
+    M, H = y.shape
+    w1 = np.ascontiguousarray(W1_bytes); w2 = np.ascontiguousarray(W2_bytes)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    b1, b2, gamma, beta = f(b1), f(b2), f(gamma), f(beta)
+    out = np.zeros((M, H), dtype=np.float16)
+    r = L.bert_hip_test_ffn(M, H, I, y.ctypes.data, w1.ctypes.data, w2.ctypes.data, wtype, b1.ctypes.data, b2.ctypes.data,
+                            gamma.ctypes.data, beta.ctypes.data, int(fused), out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_ffn failed: {r}")
     return out

@@ -73,6 +73,13 @@ BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint1
                                     int32_t wtype, const float *bias, const uint16_t *resid,
                                     int32_t epilogue, int32_t impl, uint16_t *C);
 
+/* Whole feed-forward block: out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * gamma + beta, y [M][H] f16 bits,
+ * W1 [I][H] and W2 [H][I] in file layout of `wtype`.  fused: 1 = single fused kernel (returns -2 if the
+ * shape is not supported by it), 0 = the three-kernel path (GEMM+GELU, GEMM+residual, LayerNorm).   */
+BERT_API int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2,
+                                   int32_t wtype, const float *b1, const float *b2, const float *gamma,
+                                   const float *beta, int32_t fused, uint16_t *out);
+
 /* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
 BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                          int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);

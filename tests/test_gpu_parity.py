@@ -65,6 +65,36 @@ def test_gemm_kernel(impl, ftype, shape):
         assert not bad.any(), (ftype, shape, epi, impl, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5])
 
 
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "three-kernel"])
+@pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1"])
+@pytest.mark.parametrize("M,H,I", [(200, 128, 128), (256, 256, 512), (130, 384, 1536), (384, 384, 256)])
+def test_ffn_block_kernel(fused, ftype, M, H, I):
+    """gelu(y W1^T + b1) W2^T + b2 + y -> LayerNorm, fused kernel and three-kernel path vs numpy."""
+    rng = np.random.default_rng(M + H + I)
+    y = rng.normal(0, 1, (M, H)).astype(np.float16)
+    W1 = (rng.normal(0, 1, (I, H)) / np.sqrt(H)).astype(np.float32)
+    W2 = (rng.normal(0, 1, (H, I)) / np.sqrt(I)).astype(np.float32)
+    W1[:, : H // 2] *= 1.5; W2[: H // 3] += 0.02
+    b1 = rng.normal(0, 0.5, I).astype(np.float32); b2 = rng.normal(0, 0.5, H).astype(np.float32)
+    gamma = rng.normal(1, 0.2, H).astype(np.float32); beta = rng.normal(0, 0.3, H).astype(np.float32)
+    w1b, w1d = _weight_bytes(W1, ftype)
+    w2b, w2d = _weight_bytes(W2, ftype)
+    try:
+        got = pybert.test_ffn(y, w1b, w2b, WT[ftype], I, b1, b2, gamma, beta, fused).astype(np.float64)
+    except RuntimeError as e:
+        if fused and "-2" in str(e):
+            pytest.skip("shape / weight type not handled by the fused kernel (falls back to three kernels)")
+        raise
+    y64 = y.astype(np.float64)
+    h = _gelu(y64 @ w1d.astype(np.float64).T + b1)
+    pre = h @ w2d.astype(np.float64).T + b2 + y64
+    mu = pre.mean(axis=1, keepdims=True)
+    want = (pre - mu) / np.sqrt(((pre - mu) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta
+    err = np.abs(got - want)
+    assert err.max() < 2.5e-2, (fused, ftype, M, H, I, float(err.max()), np.argwhere(err > 2.5e-2)[:5])
+    assert err.mean() < 2.5e-3
+
+
 def _attention_ref(qkv, cu, n_head, d):
     T = qkv.shape[0]
     H = n_head * d
@@ -119,7 +149,7 @@ LENS = [1, 2, 3, 17, 31, 32, 33, 48, 64]
 
 
 @pytest.mark.parametrize("ftype", ["f32", "f16", "q4_0", "q4_1"])
-@pytest.mark.parametrize("dims", ["tiny", "tiny-d64", "tiny-d16"])
+@pytest.mark.parametrize("dims", ["tiny", "tiny-d64", "tiny-d16", "tiny-h128"])
 def test_eval_matches_oracle_small(make_model, dims, ftype):
     path, hp = make_model(dims, ftype, 1)
     m = pybert.BertModel(path)
