@@ -19,6 +19,8 @@
 // makes the GELU epilogue, the residual add and the LayerNorm statistics per-lane-column work.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace bert_hip {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +38,7 @@ struct FfnArgs {
     const float *b1, *b2, *gamma, *beta;
     half_t *out;           // [T_pad][H]
     int I;
+    int ablate;            // debug (BERT_HIP_FFN_ABLATE): 1 no steady-state DMA, 2 no MFMA, 4 no fragment reads, 8 no GELU
 };
 
 constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
@@ -46,15 +49,13 @@ constexpr int FF_CONST = FF_HC + 32768;        // b1[I], then b2, gamma, beta [H
 __device__ __forceinline__ int off64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int off_hc(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 
-// 128 rows x 64 halfs (128-B rows) -> 16 KiB LDS tile; this wave moves rows [wave*16, wave*16+16)
-__device__ __forceinline__ void dma_tile8(const half_t *src, int ld, char *tile, int wave, int lane) {
+// 128 rows x 64 halfs (128-B rows) -> 16 KiB LDS tile; this wave moves rows [wave*16, wave*16+16).
+// `base` is wave-uniform (SGPR pair), `loff[i]` the lane's byte offset inside the tile's source rows,
+// so the load uses the scalar-base + 32-bit-VGPR-offset form and costs no address VGPRs per tile.
+__device__ __forceinline__ void dma_tile8(const half_t *base, const unsigned (&loff)[2], char *tile, int wave) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = wave * 2 + i;
-        const int r = g * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + (size_t)r * ld + c * 8), AS_LDS(tile + g * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + loff[i]), AS_LDS(tile + (wave * 2 + i) * 1024), 16, 0, 0);
 }
 
 __device__ __forceinline__ float gelu_fast(float x) {
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, KU = H / 64, TPC = KU + 2 * NT;
     const int I = a.I, NC = I / 128, NTILES = NC * TPC;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform -> SGPR
     const int wt = wave >> 2, wq = wave & 3;
     const int l31 = lane & 31, hi = lane >> 5;
     const int m0 = blockIdx.x * 128;
@@ -90,16 +92,26 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 
     const half_t *ybase = a.y + (size_t)m0 * H;
 
+    // lane's byte offsets inside a [128 rows x 64 halfs] source tile with row stride H (y, W1) or I (W2);
+    // the 16-byte chunk is pre-swizzled here and un-swizzled by the fragment reads (off64)
+    unsigned loffH[2], loffI[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wave * 2 + i) * 8 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        loffH[i] = (unsigned)(r * H + ch * 8) * 2u;
+        loffI[i] = (unsigned)(r * I + ch * 8) * 2u;
+    }
     // tile t -> ring slot t % 3
     auto issue = [&](int t) {
         const int c = t / TPC, p = t - c * TPC;
         char *slot = ring + (t % 3) * FF_SLOT;
         if (p < KU) {
-            dma_tile8(ybase + p * 64, H, slot, wave, lane);
-            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, H, slot + 16384, wave, lane);
+            dma_tile8(ybase + p * 64, loffH, slot, wave);
+            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, slot + 16384, wave);
         } else {
             const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
-            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, I, slot, wave, lane);
+            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, slot, wave);
         }
     };
 
@@ -108,6 +120,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     for (int i = tid; i < H; i += 512) { cb2[i] = a.b2[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
     issue(0);
     issue(1);
+
+    // per-lane LDS byte offsets of the MFMA fragments (swizzles are XORs, so one VGPR per k-step)
+    int aW[4], aY[4], aH[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        aW[kk] = off64(wq * 32 + l31, kk * 2 + hi);
+        aY[kk] = off64(wt * 64 + l31, kk * 2 + hi);
+        aH[0][kk] = off_hc(wt * 64 + l31, kk * 2 + hi);
+        aH[1][kk] = off_hc(wt * 64 + l31, 8 + kk * 2 + hi);
+    }
 
     f32x16 acc2[NT][2], accU[2];
 #pragma unroll
@@ -131,21 +153,30 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             } else {
                 wait_vm_barrier<0>();
             }
-            if (t + 2 < NTILES) issue(t + 2);       // its slot was read in interval t-1: free after the barrier
-            const char *slot = ring + (t % 3) * FF_SLOT;
+            if (t + 2 < NTILES && !(a.ablate & 1)) issue(t + 2);       // its slot was read in interval t-1: free after the barrier
             if (p < KU) {
-                // ---- U: accU += W1tile (features) x ytile (tokens)
-                const char *yT = slot, *wT = slot + 16384;
+                // ---- U: accU += W1tile (features) x ytile (tokens).  All 12 fragments of the tile are
+                // fetched before the 8 MFMAs so the matrix pipe runs back to back while the partner
+                // wave on this SIMD is in its own LDS phase.
+                const int so = (t % 3) * FF_SLOT;
+                f16x8 wf[4], a0[4], a1[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { wf[kk] = (f16x8)(_Float16)(float)kk; a0[kk] = wf[kk]; a1[kk] = wf[kk]; }
+                if (!(a.ablate & 4))
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int ch = kk * 2 + hi;
-                    const f16x8 wf = *(const f16x8 *)(wT + off64(wq * 32 + l31, ch));
-                    const f16x8 a0 = *(const f16x8 *)(yT + off64(wt * 64 + l31, ch));
-                    const f16x8 a1 = *(const f16x8 *)(yT + off64(wt * 64 + 32 + l31, ch));
-                    accU[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a0, accU[0], 0, 0, 0);
-                    accU[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a1, accU[1], 0, 0, 0);
+                    wf[kk] = *(const f16x8 *)(ring + so + 16384 + aW[kk]);
+                    a0[kk] = *(const f16x8 *)(ring + so + aY[kk]);
+                    a1[kk] = *(const f16x8 *)(ring + so + aY[kk] + 32 * 128);
                 }
-                if (p == KU - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (a.ablate & 2) { asm volatile("" :: "v"(wf[0]), "v"(a0[0]), "v"(a1[0]), "v"(wf[3]), "v"(a0[3]), "v"(a1[3])); } else
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    accU[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], accU[0], 0, 0, 0);
+                    accU[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], accU[1], 0, 0, 0);
+                }
+                if (p == KU - 1 && !(a.ablate & 8)) {
                     // ---- chunk epilogue: bias + GELU, f16, into hc[token][feature] (read by the D tiles
                     // after the next barrier; last read of the previous chunk's hc was >= KU barriers ago)
 #pragma unroll
@@ -168,16 +199,24 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
                 }
             } else {
                 // ---- D: acc2[n3] += W2tile (features) x hc (tokens), k-half k2 of the chunk
-                constexpr int dummy = 0; (void)dummy;
                 const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
+                const int so = (t % 3) * FF_SLOT;
+                f16x8 wf[4], a0[4], a1[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { wf[kk] = (f16x8)(_Float16)(float)kk; a0[kk] = wf[kk]; a1[kk] = wf[kk]; }
+                if (!(a.ablate & 4))
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const int ch = kk * 2 + hi;
-                    const f16x8 wf = *(const f16x8 *)(slot + off64(wq * 32 + l31, ch));
-                    const f16x8 a0 = *(const f16x8 *)(hc + off_hc(wt * 64 + l31, k2 * 8 + ch));
-                    const f16x8 a1 = *(const f16x8 *)(hc + off_hc(wt * 64 + 32 + l31, k2 * 8 + ch));
-                    acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a0, acc2[n3][0], 0, 0, 0);
-                    acc2[n3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, a1, acc2[n3][1], 0, 0, 0);
+                    wf[kk] = *(const f16x8 *)(ring + so + aW[kk]);
+                    a0[kk] = *(const f16x8 *)(hc + aH[k2][kk]);
+                    a1[kk] = *(const f16x8 *)(hc + aH[k2][kk] + 32 * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (a.ablate & 2) { asm volatile("" :: "v"(wf[0]), "v"(a0[0]), "v"(a1[0]), "v"(wf[3]), "v"(a0[3]), "v"(a1[3])); } else
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], acc2[n3][0], 0, 0, 0);
+                    acc2[n3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], acc2[n3][1], 0, 0, 0);
                 }
             }
         }
@@ -273,6 +312,9 @@ void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *
     FfnArgs a;
     a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
     a.I = W1.N;
+    static int ablate = -1;
+    if (ablate < 0) { const char *e = getenv("BERT_HIP_FFN_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
     const int grid = M_pad / 128;

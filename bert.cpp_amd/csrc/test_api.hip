@@ -82,6 +82,39 @@ int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, co
     return 0;
 }
 
+// micro-benchmark: average ms of one fused-FFN launch on random data (weights f16), for kernel tuning
+BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters) {
+    std::string err;
+    std::vector<uint16_t> w1((size_t)I * H), w2((size_t)H * I), yv((size_t)M * H);
+    unsigned seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (uint16_t)(0x2c00u | ((seed >> 9) & 0x83ffu)); };  // |x| in [0.06, 0.12)
+    for (auto &v : w1) v = rnd();
+    for (auto &v : w2) v = rnd();
+    for (auto &v : yv) v = (uint16_t)(rnd() + 0x1000u);
+    HostTensor t1, t2;
+    t1.type = W_F16; t1.n_dims = 2; t1.ne0 = H; t1.ne1 = I; t1.data = (const uint8_t *)w1.data(); t1.nbytes = w1.size() * 2;
+    t2.type = W_F16; t2.n_dims = 2; t2.ne0 = I; t2.ne1 = H; t2.data = (const uint8_t *)w2.data(); t2.nbytes = w2.size() * 2;
+    GemmWeightStore s1, s2;
+    if (!s1.build({&t1}, false, err) || !s2.build({&t2}, false, err) || !ffn_fused_supported(s1.w, s2.w)) return -1.f;
+    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    DevBuf dy, dout, dc;
+    std::vector<float> ones((size_t)I + H, 0.5f);
+    if (!dy.alloc((size_t)M_pad * H * 2, err) || !dout.alloc((size_t)M_pad * H * 2, err) || !dc.upload(ones.data(), ones.size() * 4, err)) return -1.f;
+    if (hipMemcpy(dy.p, yv.data(), yv.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto go = [&]() { launch_ffn_fused(s1.w, s2.w, dy.as<half_t>(), dc.as<float>(), dc.as<float>(), dc.as<float>(), dc.as<float>(), dout.as<half_t>(), M_pad, nullptr); };
+    for (int i = 0; i < 3; ++i) go();
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) go();
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return ms / iters;
+}
+
 int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
                                 const uint16_t *qkv, int32_t impl, uint16_t *out) {
     std::string err;
