@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("BERT_HIP_QUIET", "1")
 
+from bert_cpp_amd import dist as bdist  # noqa: E402
 from bert_cpp_amd import ggml_file as gf  # noqa: E402
 from bert_cpp_amd import pybert  # noqa: E402
 
@@ -64,13 +65,15 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir):
     d_tokens = torch.from_numpy(ids.reshape(-1)).to(device)
     d_cu = torch.arange(0, (B + 1) * N, N, dtype=torch.int32, device=device)
     d_out = torch.empty((B, H), dtype=torch.float32, device=device)
-    d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
     stream = torch.cuda.current_stream(device)
+    counts = [B] * world
+    gathered = {}
 
     def step():
         model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, B * N, N, d_out.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)      # RCCL over xGMI: the path's one exchange step
+            # RCCL over xGMI: the path's one exchange step (bert.cpp_amd/dist.py), [world*B, H] on every rank
+            gathered["all"] = bdist.gather_embeddings(d_out, counts)
 
     for _ in range(args.warmup):
         step()
