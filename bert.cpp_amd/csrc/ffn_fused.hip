@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace bert_hip {
 
@@ -38,7 +39,6 @@ struct FfnArgs {
     const float *b1, *b2, *gamma, *beta;
     half_t *out;           // [T_pad][H]
     int I;
-    int ablate;            // debug (BERT_HIP_FFN_ABLATE): 1 no steady-state DMA, 2 no MFMA, 4 no fragment reads, 8 no GELU
 };
 
 constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
@@ -77,7 +77,7 @@ template <int NT>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, KU = H / 64, TPC = KU + 2 * NT;
-    const int I = a.I, NC = I / 128, NTILES = NC * TPC;
+    const int I = a.I, NC = I / 128;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // provably wave-uniform -> SGPR
     const int wt = wave >> 2, wq = wave & 3;
@@ -102,24 +102,26 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         loffH[i] = (unsigned)(r * H + ch * 8) * 2u;
         loffI[i] = (unsigned)(r * I + ch * 8) * 2u;
     }
-    // tile t -> ring slot t % 3
-    auto issue = [&](int t) {
-        const int c = t / TPC, p = t - c * TPC;
-        char *slot = ring + (t % 3) * FF_SLOT;
+    // tile (chunk c, position p) -> ring slot `slot`; U tiles carry a y k-tile and a W1 k-tile, D tiles a W2 tile
+    auto issue = [&](int c, int p, int slot) {
+        char *dst = ring + slot * FF_SLOT;
         if (p < KU) {
-            dma_tile8(ybase + p * 64, loffH, slot, wave);
-            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, slot + 16384, wave);
+            // keep the (loop-invariant) y addresses out of long-lived VGPR pairs: recompute per use
+            const half_t *yb = ybase;
+            asm volatile("" : "+s"(yb));
+            dma_tile8(yb + p * 64, loffH, dst, wave);
+            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, dst + 16384, wave);
         } else {
             const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
-            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, slot, wave);
+            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, dst, wave);
         }
     };
 
     // ---- prologue: constants into LDS, first two tiles in flight
     for (int i = tid; i < I; i += 512) cb1[i] = a.b1[i];
     for (int i = tid; i < H; i += 512) { cb2[i] = a.b2[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
-    issue(0);
-    issue(1);
+    issue(0, 0, 0);
+    issue(0, 1, 1);
 
     // per-lane LDS byte offsets of the MFMA fragments (swizzles are XORs, so one VGPR per k-step)
     int aW[4], aY[4], aH[2][4];
@@ -143,40 +145,55 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
 
-    for (int c = 0; c < NC; ++c) {
+    // One chunk = TPC tiles; everything about a tile except the chunk index is a compile-time
+    // constant of its position p, so the steady state is branch-free.  LAST = final chunk (its last
+    // two tiles prefetch nothing and its last wait drains the DMA queue).
+    int sbase = 0;                                   // ring slot of the chunk's first tile
+    auto chunk = [&](auto last_tag, int c) {
+        constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
         for (int p = 0; p < TPC; ++p) {
-            const int t = c * TPC + p;
-            // tile t landed for every wave?  (tile t+1 may stay in flight: 4 pieces if U, 2 if D)
-            if (t + 1 < NTILES) {
-                if (((p + 1) % TPC) < KU) wait_vm_barrier<4>(); else wait_vm_barrier<2>();
-            } else {
-                wait_vm_barrier<0>();
-            }
-            if (t + 2 < NTILES && !(a.ablate & 1)) issue(t + 2);       // its slot was read in interval t-1: free after the barrier
+            int slot = sbase + (p % 3);
+            slot = slot >= 3 ? slot - 3 : slot;
+            // tile landed for every wave?  (the next tile may stay in flight: 4 pieces if U, 2 if D)
+            if (LAST && p == TPC - 1) wait_vm_barrier<0>();
+            else if (((p + 1) % TPC) < KU) wait_vm_barrier<4>();
+            else wait_vm_barrier<2>();
+            const int so = slot * FF_SLOT;
+            f16x8 wf[4], a0[4], a1[4];
             if (p < KU) {
-                // ---- U: accU += W1tile (features) x ytile (tokens).  All 12 fragments of the tile are
-                // fetched before the 8 MFMAs so the matrix pipe runs back to back while the partner
-                // wave on this SIMD is in its own LDS phase.
-                const int so = (t % 3) * FF_SLOT;
-                f16x8 wf[4], a0[4], a1[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { wf[kk] = (f16x8)(_Float16)(float)kk; a0[kk] = wf[kk]; a1[kk] = wf[kk]; }
-                if (!(a.ablate & 4))
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     wf[kk] = *(const f16x8 *)(ring + so + 16384 + aW[kk]);
                     a0[kk] = *(const f16x8 *)(ring + so + aY[kk]);
                     a1[kk] = *(const f16x8 *)(ring + so + aY[kk] + 32 * 128);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (a.ablate & 2) { asm volatile("" :: "v"(wf[0]), "v"(a0[0]), "v"(a1[0]), "v"(wf[3]), "v"(a0[3]), "v"(a1[3])); } else
+            } else {
+                const int k2 = (p - KU) & 1;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    wf[kk] = *(const f16x8 *)(ring + so + aW[kk]);
+                    a0[kk] = *(const f16x8 *)(hc + aH[k2][kk]);
+                    a1[kk] = *(const f16x8 *)(hc + aH[k2][kk] + 32 * 256);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // prefetch tile +2 into the slot that was read one interval ago (free since the barrier above)
+            if (!(LAST && p + 2 >= TPC)) {
+                int s2 = slot + 2;
+                s2 = s2 >= 3 ? s2 - 3 : s2;
+                if (p + 2 < TPC) issue(c, p + 2, s2); else issue(c + 1, p + 2 - TPC, s2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (p < KU) {
+                // ---- U: accU += W1 tile (features) x y tile (tokens); fragments were all fetched above so
+                // the 8 MFMAs issue back to back
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     accU[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], accU[0], 0, 0, 0);
                     accU[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], accU[1], 0, 0, 0);
                 }
-                if (p == KU - 1 && !(a.ablate & 8)) {
+                if (p == KU - 1) {
                     // ---- chunk epilogue: bias + GELU, f16, into hc[token][feature] (read by the D tiles
                     // after the next barrier; last read of the previous chunk's hc was >= KU barriers ago)
 #pragma unroll
@@ -198,21 +215,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
                         for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
                 }
             } else {
-                // ---- D: acc2[n3] += W2tile (features) x hc (tokens), k-half k2 of the chunk
-                const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
-                const int so = (t % 3) * FF_SLOT;
-                f16x8 wf[4], a0[4], a1[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { wf[kk] = (f16x8)(_Float16)(float)kk; a0[kk] = wf[kk]; a1[kk] = wf[kk]; }
-                if (!(a.ablate & 4))
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    wf[kk] = *(const f16x8 *)(ring + so + aW[kk]);
-                    a0[kk] = *(const f16x8 *)(hc + aH[k2][kk]);
-                    a1[kk] = *(const f16x8 *)(hc + aH[k2][kk] + 32 * 256);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (a.ablate & 2) { asm volatile("" :: "v"(wf[0]), "v"(a0[0]), "v"(a1[0]), "v"(wf[3]), "v"(a0[3]), "v"(a1[3])); } else
+                // ---- D: acc2[n3] += W2 tile (features) x hc (tokens), k-half k2 of the chunk
+                const int n3 = (p - KU) >> 1;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], acc2[n3][0], 0, 0, 0);
@@ -220,7 +224,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
                 }
             }
         }
-    }
+        sbase += TPC % 3;
+        sbase = sbase >= 3 ? sbase - 3 : sbase;
+    };
+    for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
+    chunk(std::true_type{}, NC - 1);
 
     // ---- final epilogue: + b2 + residual, LayerNorm over H per token, gamma/beta, store.
     // lane owns tokens tok_j = wt*64 + j*32 + l31 and features f = n*128 + wq*32 + 8g + 4hi + e
@@ -312,9 +320,6 @@ void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *
     FfnArgs a;
     a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
     a.I = W1.N;
-    static int ablate = -1;
-    if (ablate < 0) { const char *e = getenv("BERT_HIP_FFN_ABLATE"); ablate = e ? atoi(e) : 0; }
-    a.ablate = ablate;
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
     const int grid = M_pad / 128;
