@@ -171,6 +171,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *g = getenv("BERT_HIP_GEMM")) e->gemm_naive_ = strcmp(g, "naive") == 0;
     if (const char *a = getenv("BERT_HIP_ATTN")) e->attn_naive_ = strcmp(a, "naive") == 0;
     if (const char *f = getenv("BERT_HIP_FFN")) e->ffn_fused_ = strcmp(f, "unfused") != 0;
+    if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -224,6 +225,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
         gemm_naive_ = value == "naive";
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "ffn") ffn_fused_ = value != "unfused";
+    else if (key == "panel") panel_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -305,13 +307,22 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const double att_flops = 4.0 * Td * max_len * H;
     for (int il = 0; il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
-        gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
+        if (panel_ && !gemm_naive_ && L.qkv.mfma_ok && panel_gemm_supported(L.qkv.w, false))
+            timed("panel_qkv", 2.0 * Td * L.qkv.w.N * L.qkv.w.K, s, [&] { launch_panel_store(L.qkv.w, x, L.qkv_b.as<float>(), qkv, t_pad, s); });
+        else
+            gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
         timed("attention", att_flops, s, [&] {
             if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
                 launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
         });
-        gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
-        timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
+        if (panel_ && !gemm_naive_ && L.o.mfma_ok && panel_gemm_supported(L.o.w, true)) {
+            timed("proj_ln", 2.0 * Td * L.o.w.N * L.o.w.K, s, [&] {
+                launch_proj_ln(L.o.w, ctx, L.o_b.as<float>(), x, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), y, t_pad, s);
+            });
+        } else {
+            gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
+            timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
+        }
         if (ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w)) {
             timed("ffn_fused", 4.0 * Td * H * I, s, [&] {
                 launch_ffn_fused(L.ffi.w, L.ffo.w, y, L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(),

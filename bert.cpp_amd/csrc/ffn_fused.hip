@@ -17,20 +17,12 @@
 // between the 12 x (H/64 + 2 H/128) tiles of a workgroup.  MFMA operand roles are as in gemm.hip
 // (weights = A operand, activations = B operand: a lane's accumulator column is one token), which
 // makes the GELU epilogue, the residual add and the LayerNorm statistics per-lane-column work.
-#include "kernels.h"
+#include "tile_stream.h"
 
 #include <cstdlib>
 #include <type_traits>
 
 namespace bert_hip {
-
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define AS_GLOBAL(p) ((const __attribute__((address_space(1))) void *)(p))
-#define AS_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 
 struct FfnArgs {
     const half_t *y;       // [T_pad][H]   LayerNorm'ed attention output (input and residual)
@@ -39,39 +31,8 @@ struct FfnArgs {
     const float *b1, *b2, *gamma, *beta;
     half_t *out;           // [T_pad][H]
     int I;
+    int skip;              // tuning aid (BERT_HIP_FFN_SKIP): 1 = no final epilogue, 2 = no main loop
 };
-
-constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
-constexpr int FF_RING = 3 * FF_SLOT;
-constexpr int FF_HC = FF_RING;                 // [128][128] f16 = 32 KiB
-constexpr int FF_CONST = FF_HC + 32768;        // b1[I], then b2, gamma, beta [H], then LN scratch
-
-__device__ __forceinline__ int off64(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-__device__ __forceinline__ int off_hc(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
-
-// 128 rows x 64 halfs (128-B rows) -> 16 KiB LDS tile; this wave moves rows [wave*16, wave*16+16).
-// `base` is wave-uniform (SGPR pair), `loff[i]` the lane's byte offset inside the tile's source rows,
-// so the load uses the scalar-base + 32-bit-VGPR-offset form and costs no address VGPRs per tile.
-__device__ __forceinline__ void dma_tile8(const half_t *base, const unsigned (&loff)[2], char *tile, int wave) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + loff[i]), AS_LDS(tile + (wave * 2 + i) * 1024), 16, 0, 0);
-}
-
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
-    const float c2 = c1 * 0.044715f;
-    const float t = x * __builtin_fmaf(x * x, c2, c1);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-}
-
-template <int G>
-__device__ __forceinline__ void wait_vm_barrier() {
-    // retire everything but the newest G DMA pieces of this wave, make own LDS writes visible, sync
-    if (G == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else if (G == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 template <int NT>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
@@ -227,86 +188,16 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         sbase += TPC % 3;
         sbase = sbase >= 3 ? sbase - 3 : sbase;
     };
-    for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
-    chunk(std::true_type{}, NC - 1);
+    if (!(a.skip & 2)) {
+        for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
+        chunk(std::true_type{}, NC - 1);
+    } else {
+        wait_vm_barrier<0>();
+    }
+    if (a.skip & 1) { if (acc2[0][0][0] == 12345.f) a.out[0] = (_Float16)1; return; }
 
-    // ---- final epilogue: + b2 + residual, LayerNorm over H per token, gamma/beta, store.
-    // lane owns tokens tok_j = wt*64 + j*32 + l31 and features f = n*128 + wq*32 + 8g + 4hi + e
-    float sum[2] = {0.f, 0.f};
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f0 = n * 128 + wq * 32 + 8 * g + 4 * hi;
-            const f32x4 bv = *(const f32x4 *)(cb2 + f0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int tok = wt * 64 + j * 32 + l31;
-                const f16x4 rv = *(const f16x4 *)(ybase + (size_t)tok * H + f0);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc2[n][j][4 * g + e] + bv[e] + (float)rv[e];
-                    acc2[n][j][4 * g + e] = v;
-                    sum[j] += v;
-                }
-            }
-        }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // all waves are past their last ring / hc read
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        sum[j] += __shfl_xor(sum[j], 32);
-        if (hi == 0) red[wq * 128 + wt * 64 + j * 32 + l31] = sum[j];
-    }
-    __syncthreads();
-    float mean[2], sq[2] = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tok = wt * 64 + j * 32 + l31;
-        mean[j] = ((red[tok] + red[128 + tok]) + (red[256 + tok] + red[384 + tok])) * (1.0f / H);
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc2[n][j][r] - mean[j];
-                acc2[n][j][r] = d;
-                sq[j] += d * d;
-            }
-    __syncthreads();                                           // everyone has read the sums
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        sq[j] += __shfl_xor(sq[j], 32);
-        if (hi == 0) red[wq * 128 + wt * 64 + j * 32 + l31] = sq[j];
-    }
-    __syncthreads();
-    half_t *Cs = (half_t *)ring;                               // [128 tokens][H] f16, 16-B chunk ^ (tok & 15)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int tok = wt * 64 + j * 32 + l31;
-        const float var = ((red[tok] + red[128 + tok]) + (red[256 + tok] + red[384 + tok])) * (1.0f / H);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f);
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int f0 = n * 128 + wq * 32 + 8 * g + 4 * hi;
-                const f32x4 gv = *(const f32x4 *)(cg + f0), bv = *(const f32x4 *)(cbeta + f0);
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)(gv[e] * (acc2[n][j][4 * g + e] * rstd) + bv[e]);
-                const int chunk = f0 >> 3;
-                *(f16x4 *)(Cs + (size_t)tok * H + (((chunk & ~15) | ((chunk ^ tok) & 15)) << 3) + (f0 & 4)) = o;
-            }
-    }
-    __syncthreads();
-    constexpr int CPR = H / 8;                                 // 16-byte chunks per row
-    for (int idx = tid; idx < 128 * CPR; idx += 512) {
-        const int tok = idx / CPR, chunk = idx - tok * CPR;
-        const uint4 v = *(const uint4 *)(Cs + (size_t)tok * H + (((chunk & ~15) | ((chunk ^ tok) & 15)) << 3));
-        *(uint4 *)(a.out + ((size_t)m0 + tok) * H + chunk * 8) = v;
-    }
+    // ---- final epilogue: + b2 + residual (the block input y), LayerNorm, gamma/beta, full-row stores
+    ln_epilogue<NT>(acc2, cb2, cg, cbeta, red, ybase, a.out + (size_t)m0 * H, ring, tid, wt, wq, l31, hi);
 }
 
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
@@ -320,6 +211,9 @@ void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *
     FfnArgs a;
     a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
     a.I = W1.N;
+    static int skip = -1;
+    if (skip < 0) { const char *e = getenv("BERT_HIP_FFN_SKIP"); skip = e ? atoi(e) : 0; }
+    a.skip = skip;
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
     const int grid = M_pad / 128;
