@@ -26,15 +26,17 @@ namespace bert_hip {
 
 struct FfnArgs {
     const half_t *y;       // [T_pad][H]   LayerNorm'ed attention output (input and residual)
-    const half_t *w1;      // [I_pad][H]   f16
+    const half_t *w1;      // [I_pad][H]   f16            (WT == GW_F16)
     const half_t *w2;      // [H_pad][I]   f16
+    const uint4 *q1, *q2;  // q4 nibble planes of W1 / W2 (WT != GW_F16), tile-contiguous (kernels.h)
+    const void *s1, *s2;   // q4 scale planes
     const float *b1, *b2, *gamma, *beta;
     half_t *out;           // [T_pad][H]
     int I;
     int skip;              // tuning aid (BERT_HIP_FFN_SKIP): 1 = no final epilogue, 2 = no main loop
 };
 
-template <int NT>
+template <int NT, int WT>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, KU = H / 64, TPC = KU + 2 * NT;
@@ -63,7 +65,10 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         loffH[i] = (unsigned)(r * H + ch * 8) * 2u;
         loffI[i] = (unsigned)(r * I + ch * 8) * 2u;
     }
-    // tile (chunk c, position p) -> ring slot `slot`; U tiles carry a y k-tile and a W1 k-tile, D tiles a W2 tile
+    // tile (chunk c, position p) -> ring slot `slot`; U tiles carry a y k-tile and a W1 k-tile, D tiles a W2
+    // tile.  f16 weights travel by LDS-DMA like the activations; q4 weights are fetched into `pend` (two
+    // ordinary loads per thread) and expanded into their slot by commit() one interval later.
+    QRegs pend = {{0, 0, 0, 0}, 0};
     auto issue = [&](int c, int p, int slot) {
         char *dst = ring + slot * FF_SLOT;
         if (p < KU) {
@@ -71,18 +76,25 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             const half_t *yb = ybase;
             asm volatile("" : "+s"(yb));
             dma_tile8(yb + p * 64, loffH, dst, wave);
-            dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, dst + 16384, wave);
+            if (WT == GW_F16) dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, dst + 16384, wave);
+            else pend = q4_fetch<WT>(a.q1, a.s1, (size_t)c * KU + p, tid);
         } else {
             const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
-            dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, dst, wave);
+            if (WT == GW_F16) dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, dst, wave);
+            else pend = q4_fetch<WT>(a.q2, a.s2, (size_t)n3 * (I / 64) + 2 * c + k2, tid);
         }
+    };
+    // expand the pending q4 tile (position p) into its slot
+    auto commit = [&](int p, int slot) {
+        if (WT != GW_F16) q4_expand_to_lds<WT>(pend, ring + slot * FF_SLOT + (p < KU ? 16384 : 0), tid);
     };
 
     // ---- prologue: constants into LDS, first two tiles in flight
     for (int i = tid; i < I; i += 512) cb1[i] = a.b1[i];
     for (int i = tid; i < H; i += 512) { cb2[i] = a.b2[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
     issue(0, 0, 0);
-    issue(0, 1, 1);
+    commit(0, 0);
+    issue(0, 1, 1);                                  // its q4 part is committed in interval 0
 
     // per-lane LDS byte offsets of the MFMA fragments (swizzles are XORs, so one VGPR per k-step)
     int aW[4], aY[4], aH[2][4];
@@ -120,6 +132,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             if (LAST && p == TPC - 1) wait_vm_barrier<0>();
             else if (((p + 1) % TPC) < KU) wait_vm_barrier<4>();
             else wait_vm_barrier<2>();
+            // q4: the weights of tile +1 were fetched one interval ago; expand them into their (free) slot now
+            if (WT != GW_F16 && !(LAST && p + 1 >= TPC)) {
+                int s1 = slot + 1;
+                s1 = s1 >= 3 ? s1 - 3 : s1;
+                commit((p + 1) % TPC, s1);
+            }
             const int so = slot * FF_SLOT;
             f16x8 wf[4], a0[4], a1[4];
             if (p < KU) {
@@ -202,14 +220,13 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
     const int H = W1.K, I = W1.N;
-    return W1.type == GW_F16 && W2.type == GW_F16 && W2.N == H && W2.K == I && H % 128 == 0 && H <= 384 &&
-           I % 128 == 0 && I <= 6144;
+    return W1.type == W2.type && W2.N == H && W2.K == I && H % 128 == 0 && H <= 384 && I % 128 == 0 && I <= 6144;
 }
 
 void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
                       const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream) {
     FfnArgs a;
-    a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.q1 = W1.qs; a.q2 = W2.qs; a.s1 = W1.sc; a.s2 = W2.sc; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
     a.I = W1.N;
     static int skip = -1;
     if (skip < 0) { const char *e = getenv("BERT_HIP_FFN_SKIP"); skip = e ? atoi(e) : 0; }
@@ -217,18 +234,22 @@ void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
     const int grid = M_pad / 128;
-    static bool configured[4] = {false, false, false, false};
-    auto cfg = [&](const void *fn, int nt) {
-        if (!configured[nt]) {
-            hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured[nt] = true;
+    static bool configured[3][4] = {};
+    auto go = [&](auto kernel, int nt) {
+        if (!configured[W1.type][nt]) {
+            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured[W1.type][nt] = true;
         }
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
-    switch (H / 128) {
-        case 1: cfg((const void *)ffn_fused_kernel<1>, 1); hipLaunchKernelGGL(ffn_fused_kernel<1>, dim3(grid), dim3(512), lds, stream, a); break;
-        case 2: cfg((const void *)ffn_fused_kernel<2>, 2); hipLaunchKernelGGL(ffn_fused_kernel<2>, dim3(grid), dim3(512), lds, stream, a); break;
-        default: cfg((const void *)ffn_fused_kernel<3>, 3); hipLaunchKernelGGL(ffn_fused_kernel<3>, dim3(grid), dim3(512), lds, stream, a); break;
+#define FFN_NT(WTV)                                                                    \
+    switch (H / 128) {                                                                  \
+        case 1: go(ffn_fused_kernel<1, WTV>, 1); break;                                 \
+        case 2: go(ffn_fused_kernel<2, WTV>, 2); break;                                 \
+        default: go(ffn_fused_kernel<3, WTV>, 3); break;                                \
     }
+    if (W1.type == GW_F16) { FFN_NT(GW_F16) } else if (W1.type == GW_Q4_0) { FFN_NT(GW_Q4_0) } else { FFN_NT(GW_Q4_1) }
+#undef FFN_NT
 }
 
 }  // namespace bert_hip

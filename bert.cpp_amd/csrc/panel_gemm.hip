@@ -10,14 +10,17 @@
 //   panel_store_kernel   C = A W^T + b for any N (multiple of 8): the fused Q|K|V projection of
 //                        reference bert.cpp:822-839; each finished 128x128 tile is transposed through
 //                        LDS and written as full 256-byte rows while the next tiles stream in.
-// f16 weights only; q4 weights (and shapes outside these limits) use gemm.hip.
+// f16 weights stream by LDS-DMA, q4_0 / q4_1 weights are expanded in registers on their way into the ring;
+// shapes outside the limits of panel_gemm_supported() use gemm.hip.
 #include "tile_stream.h"
 
 namespace bert_hip {
 
 struct PanelArgs {
     const half_t *A;        // [T_pad][K]
-    const half_t *W;        // [N_pad][K] f16
+    const half_t *W;        // [N_pad][K] f16            (WT == GW_F16)
+    const uint4 *qs;        // q4 nibble plane, tile-contiguous (kernels.h)   (WT != GW_F16)
+    const void *sc;         // q4 scale plane
     const float *bias;      // [N]
     const half_t *resid;    // [T_pad][N]       (proj_ln)
     const float *gamma, *beta;
@@ -61,14 +64,20 @@ __device__ __forceinline__ void mma_slot(const char *slot, const int (&aW)[4], c
         aW[kk] = off64(wq * 32 + l31, kk * 2 + hi);                                                \
         aY[kk] = off64(wt * 64 + l31, kk * 2 + hi);                                                \
     }                                                                                              \
-    /* tile t = (feature tile nt = t / KT, k-tile k = t % KT) -> ring slot */                      \
+    /* tile t = (feature tile nt = t / KT, k-tile k = t % KT) -> ring slot; q4 weights go through   */ \
+    /* `pend` and are expanded into the slot by commit() one interval later (see ffn_fused.hip)     */ \
+    QRegs pend = {{0, 0, 0, 0}, 0};                                                                \
     auto issue = [&](int nt, int k, int slot) {                                                    \
         char *dst = ring + slot * FF_SLOT;                                                         \
         dma_tile8(Abase + k * 64, loffK, dst, wave);                                               \
-        dma_tile8(a.W + (size_t)nt * 128 * K + k * 64, loffK, dst + 16384, wave);                  \
+        if (WT == GW_F16) dma_tile8(a.W + (size_t)nt * 128 * K + k * 64, loffK, dst + 16384, wave); \
+        else pend = q4_fetch<WT>(a.qs, a.sc, (size_t)nt * KT + k, tid);                            \
+    };                                                                                             \
+    auto commit = [&](int slot) {                                                                  \
+        if (WT != GW_F16) q4_expand_to_lds<WT>(pend, ring + slot * FF_SLOT + 16384, tid);          \
     };
 
-template <int NT>
+template <int NT, int WT>
 __global__ __launch_bounds__(512, 2) void proj_ln_kernel(PanelArgs a) {
     PANEL_COMMON_SETUP
     constexpr int H = 128 * NT;
@@ -76,7 +85,8 @@ __global__ __launch_bounds__(512, 2) void proj_ln_kernel(PanelArgs a) {
     for (int i = tid; i < H; i += 512) { cb[i] = a.bias[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
     const int ntiles = NT * KT;
     issue(0, 0, 0);
-    if (ntiles > 1) issue(KT > 1 ? 0 : 1, KT > 1 ? 1 : 0, 1);
+    commit(0);
+    if (ntiles > 1) issue(KT > 1 ? 0 : 1, KT > 1 ? 1 : 0, 1);    // its q4 part is committed in interval 0
 
     f32x16 acc[NT][2];
 #pragma unroll
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(512, 2) void proj_ln_kernel(PanelArgs a) {
     for (int n = 0; n < NT; ++n) {
         for (int k = 0; k < KT; ++k, ++t) {
             if (t + 1 < ntiles) wait_vm_barrier<4>(); else wait_vm_barrier<0>();
+            if (t + 1 < ntiles) commit(slot == 2 ? 0 : slot + 1);
             if (t + 2 < ntiles) {
                 int s2 = slot + 2; s2 = s2 >= 3 ? s2 - 3 : s2;
                 issue(nt2, k2, s2);
@@ -104,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void proj_ln_kernel(PanelArgs a) {
     ln_epilogue<NT>(acc, cb, cg, cbeta, red, a.resid + (size_t)m0 * H, a.out + (size_t)m0 * H, ring, tid, wt, wq, l31, hi);
 }
 
+template <int WT>
 __global__ __launch_bounds__(512, 2) void panel_store_kernel(PanelArgs a) {
     PANEL_COMMON_SETUP
     const int N = a.N, NTN = (N + 127) / 128;
@@ -112,7 +124,8 @@ __global__ __launch_bounds__(512, 2) void panel_store_kernel(PanelArgs a) {
     for (int i = tid; i < NTN * 128; i += 512) cb[i] = i < N ? a.bias[i] : 0.f;
     const int ntiles = NTN * KT;
     issue(0, 0, 0);
-    if (ntiles > 1) issue(KT > 1 ? 0 : 1, KT > 1 ? 1 : 0, 1);
+    commit(0);
+    if (ntiles > 1) issue(KT > 1 ? 0 : 1, KT > 1 ? 1 : 0, 1);    // its q4 part is committed in interval 0
 
     f32x16 acc[2];
 #pragma unroll
@@ -135,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void panel_store_kernel(PanelArgs a) {
     for (int nt = 0; nt < NTN; ++nt) {
         for (int k = 0; k < KT; ++k, ++t) {
             if (t + 1 < ntiles) wait_vm_barrier<4>(); else wait_vm_barrier<0>();
+            if (t + 1 < ntiles) commit(slot == 2 ? 0 : slot + 1);
             // the previous feature tile was staged before this barrier: write it out first, so that the
             // stores are OLDER than the DMA pieces issued below (keeps the counted waits tight)
             if (k == 0 && nt > 0) flush(nt - 1);
@@ -168,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void panel_store_kernel(PanelArgs a) {
 }
 
 bool panel_gemm_supported(const GemmWeight &W, bool with_ln) {
-    if (W.type != GW_F16 || W.K % 64 != 0 || W.K < 64) return false;
+    if (W.K % 64 != 0 || W.K < 64) return false;
     if (with_ln) return W.N % 128 == 0 && W.N <= 384;
     return W.N % 8 == 0 && W.N_pad <= 8192;
 }
@@ -176,28 +190,45 @@ bool panel_gemm_supported(const GemmWeight &W, bool with_ln) {
 void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, const float *gamma,
                     const float *beta, half_t *out, int M_pad, hipStream_t stream) {
     PanelArgs a;
-    a.A = A; a.W = W.w16; a.bias = bias; a.resid = resid; a.gamma = gamma; a.beta = beta; a.out = out; a.N = W.N; a.K = W.K;
+    a.A = A; a.W = W.w16; a.qs = W.qs; a.sc = W.sc; a.bias = bias; a.resid = resid; a.gamma = gamma; a.beta = beta; a.out = out;
+    a.N = W.N; a.K = W.K;
     const int NT = W.N / 128;
     const size_t lds = FF_RING + (size_t)(3 * W.N + 512) * sizeof(float);
-    static bool configured[4] = {false, false, false, false};
-    auto cfg = [&](const void *fn) {
-        if (!configured[NT]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured[NT] = true; }
-    };
     const dim3 grid(M_pad / 128), block(512);
-    switch (NT) {
-        case 1: cfg((const void *)proj_ln_kernel<1>); hipLaunchKernelGGL(proj_ln_kernel<1>, grid, block, lds, stream, a); break;
-        case 2: cfg((const void *)proj_ln_kernel<2>); hipLaunchKernelGGL(proj_ln_kernel<2>, grid, block, lds, stream, a); break;
-        default: cfg((const void *)proj_ln_kernel<3>); hipLaunchKernelGGL(proj_ln_kernel<3>, grid, block, lds, stream, a); break;
+    static bool configured[3][4] = {};
+    auto go = [&](auto kernel) {
+        if (!configured[W.type][NT]) {
+            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured[W.type][NT] = true;
+        }
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+    };
+#define PROJ_NT(WTV)                                                     \
+    switch (NT) {                                                         \
+        case 1: go(proj_ln_kernel<1, WTV>); break;                        \
+        case 2: go(proj_ln_kernel<2, WTV>); break;                        \
+        default: go(proj_ln_kernel<3, WTV>); break;                       \
     }
+    if (W.type == GW_F16) { PROJ_NT(GW_F16) } else if (W.type == GW_Q4_0) { PROJ_NT(GW_Q4_0) } else { PROJ_NT(GW_Q4_1) }
+#undef PROJ_NT
 }
 
 void launch_panel_store(const GemmWeight &W, const half_t *A, const float *bias, half_t *out, int M_pad, hipStream_t stream) {
     PanelArgs a;
-    a.A = A; a.W = W.w16; a.bias = bias; a.resid = nullptr; a.gamma = nullptr; a.beta = nullptr; a.out = out; a.N = W.N; a.K = W.K;
+    a.A = A; a.W = W.w16; a.qs = W.qs; a.sc = W.sc; a.bias = bias; a.resid = nullptr; a.gamma = nullptr; a.beta = nullptr; a.out = out;
+    a.N = W.N; a.K = W.K;
     const size_t lds = FF_RING + 32768 + (size_t)W.N_pad * sizeof(float);
-    static bool configured = false;
-    if (!configured) { hipFuncSetAttribute((const void *)panel_store_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); configured = true; }
-    hipLaunchKernelGGL(panel_store_kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
+    static bool configured[3] = {};
+    auto go = [&](auto kernel) {
+        if (!configured[W.type]) {
+            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured[W.type] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
+    };
+    if (W.type == GW_F16) go(panel_store_kernel<GW_F16>);
+    else if (W.type == GW_Q4_0) go(panel_store_kernel<GW_Q4_0>);
+    else go(panel_store_kernel<GW_Q4_1>);
 }
 
 }  // namespace bert_hip

@@ -28,7 +28,7 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     t.nbytes = wtype_row_bytes(wtype, K) * (size_t)N;
     GemmWeightStore ws;
     if (!ws.build({&t}, impl == 1, err)) { fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str()); return -1; }
-    if (impl == 0 && !ws.mfma_ok) { fprintf(stderr, "bert_hip_test_gemm: shape not supported by the MFMA path\n"); return -2; }
+    if (impl != 1 && !ws.mfma_ok) { fprintf(stderr, "bert_hip_test_gemm: shape not supported by the MFMA path\n"); return -2; }
     const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
     DevBuf dA, dB, dR, dC;
     if (!dA.alloc((size_t)M_pad * K * 2, err) || !dC.alloc((size_t)M_pad * N * 2, err) || !dB.upload(bias, (size_t)N * 4, err)) {
@@ -40,7 +40,10 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
         if (!dR.alloc((size_t)M_pad * N * 2, err)) return -1;
         CK(hipMemcpy(dR.p, resid, (size_t)M * N * 2, hipMemcpyHostToDevice));
     }
-    if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
+    if (impl == 2) {
+        if (epilogue != EPI_BIAS || !ws.mfma_ok || !panel_gemm_supported(ws.w, false)) return -2;
+        launch_panel_store(ws.w, dA.as<half_t>(), dB.as<float>(), dC.as<half_t>(), M_pad, nullptr);
+    } else if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     else launch_gemm_naive(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M, epilogue, nullptr);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
@@ -79,6 +82,35 @@ int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, co
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out, dout.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype, const float *bias,
+                              const uint16_t *resid, const float *gamma, const float *beta, int32_t fused, uint16_t *out) {
+    std::string err;
+    HostTensor t;
+    t.type = wtype; t.n_dims = 2; t.ne0 = K; t.ne1 = N; t.data = (const uint8_t *)W; t.nbytes = wtype_row_bytes(wtype, K) * (size_t)N;
+    GemmWeightStore ws;
+    if (!ws.build({&t}, false, err)) { fprintf(stderr, "bert_hip_test_proj_ln: %s\n", err.c_str()); return -1; }
+    if (!ws.mfma_ok || (fused && !panel_gemm_supported(ws.w, true))) return -2;
+    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    DevBuf dA, dR, dO, db, dg, dbt;
+    if (!dA.alloc((size_t)M_pad * K * 2, err) || !dR.alloc((size_t)M_pad * N * 2, err) || !dO.alloc((size_t)M_pad * N * 2, err) ||
+        !db.upload(bias, (size_t)N * 4, err) || !dg.upload(gamma, (size_t)N * 4, err) || !dbt.upload(beta, (size_t)N * 4, err)) {
+        fprintf(stderr, "bert_hip_test_proj_ln: %s\n", err.c_str());
+        return -1;
+    }
+    CK(hipMemcpy(dA.p, A, (size_t)M * K * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR.p, resid, (size_t)M * N * 2, hipMemcpyHostToDevice));
+    if (fused) {
+        launch_proj_ln(ws.w, dA.as<half_t>(), db.as<float>(), dR.as<half_t>(), dg.as<float>(), dbt.as<float>(), dO.as<half_t>(), M_pad, nullptr);
+    } else {
+        launch_gemm_mfma(ws.w, dA.as<half_t>(), db.as<float>(), dR.as<half_t>(), dO.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
+        launch_layernorm(dO.as<half_t>(), dg.as<float>(), dbt.as<float>(), M, N, nullptr);
+    }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dO.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
     return 0;
 }
 

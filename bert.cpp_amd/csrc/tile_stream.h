@@ -34,6 +34,61 @@ __device__ __forceinline__ void dma_tile8(const half_t *base, const unsigned (&l
         __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + loff[i]), AS_LDS(tile + (wave * 2 + i) * 1024), 16, 0, 0);
 }
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// ---- q4_0 / q4_1 weight tiles (layout: kernels.h GemmWeight).  A [128 rows x 64 k] tile is 256 blocks of
+// 32 weights; with 512 threads, thread tid dequantises HALF a block: row = tid >> 2, block = (tid >> 1) & 1,
+// half = tid & 1 (0 = low nibbles = elements 0-15, 1 = high nibbles = elements 16-31).  The 16 bytes of
+// nibbles + the scale are fetched with two ordinary loads one interval before they are needed and expanded
+// in registers: v_perm_b32 builds (1024 + q) half pairs, packed f16 math applies (q - 8) * d or q * d + m.
+struct QRegs { uint4 q; unsigned sc; };
+
+template <int WT>
+__device__ __forceinline__ QRegs q4_fetch(const uint4 *qs, const void *sc, size_t tile_index, int tid) {
+    const size_t bi = tile_index * 256 + (tid >> 1);
+    QRegs r;
+    r.q = qs[bi];
+    r.sc = WT == GW_Q4_0 ? (unsigned)((const unsigned short *)sc)[bi] : ((const unsigned *)sc)[bi];
+    return r;
+}
+
+template <int WT>
+__device__ __forceinline__ void q4_expand_to_lds(const QRegs &r, char *tile, int tid) {
+    const int row = tid >> 2, blk = (tid >> 1) & 1, half = tid & 1;
+    const unsigned w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+    f16x2 d2, m2;
+    if (WT == GW_Q4_0) {
+        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(r.sc & 0xffffu));
+        d2 = (f16x2){d, d};
+        m2 = (f16x2){(_Float16)0, (_Float16)0};
+    } else {
+        const f16x2 dm = __builtin_bit_cast(f16x2, r.sc);
+        d2 = (f16x2){dm[0], dm[0]};
+        m2 = (f16x2){dm[1], dm[1]};
+    }
+    const f16x2 off = WT == GW_Q4_0 ? (f16x2){(_Float16)1032.0f, (_Float16)1032.0f}
+                                     : (f16x2){(_Float16)1024.0f, (_Float16)1024.0f};
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        unsigned o[4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned word = w[jj * 2 + u];
+            const unsigned n4 = (half ? (word >> 4) : word) & 0x0f0f0f0fu;
+            const unsigned p01 = __builtin_amdgcn_perm(0x64646464u, n4, 0x04010400u);
+            const unsigned p23 = __builtin_amdgcn_perm(0x64646464u, n4, 0x04030402u);
+            f16x2 v0 = __builtin_bit_cast(f16x2, p01) - off, v1 = __builtin_bit_cast(f16x2, p23) - off;
+            if (WT == GW_Q4_0) { v0 = v0 * d2; v1 = v1 * d2; }
+            else { v0 = v0 * d2 + m2; v1 = v1 * d2 + m2; }
+            o[2 * u] = __builtin_bit_cast(unsigned, v0);
+            o[2 * u + 1] = __builtin_bit_cast(unsigned, v1);
+        }
+        uint4 out;
+        out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
+        *(uint4 *)(tile + off64(row, blk * 4 + half * 2 + jj)) = out;
+    }
+}
+
 __device__ __forceinline__ float gelu_fast(float x) {
     const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
     const float c2 = c1 * 0.044715f;

@@ -24,7 +24,7 @@ BERT_HIP_H_SYMBOLS = [
     "bert_hip_load_tokenizer", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
-    "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_version",
+    "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_version",
 ]
 
 
@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
     L.bert_hip_set_option.restype = None; L.bert_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
+    L.bert_hip_test_proj_ln.restype = i32
+    L.bert_hip_test_proj_ln.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.bert_hip_test_ffn.restype = i32
     L.bert_hip_test_ffn.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.bert_hip_test_attention.restype = i32
@@ -244,4 +246,20 @@ def test_ffn(y: np.ndarray, W1_bytes: np.ndarray, W2_bytes: np.ndarray, wtype: i
                             gamma.ctypes.data, beta.ctypes.data, int(fused), out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_ffn failed: {r}")
+    return out
+
+
+def test_proj_ln(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias, resid, gamma, beta, fused: bool) -> np.ndarray:
+    L = lib()
+    A = np.ascontiguousarray(A, dtype=np.float16)
+    M, K = A.shape
+    wb = np.ascontiguousarray(W_bytes)
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    bias, gamma, beta = f(bias), f(gamma), f(beta)
+    resid = np.ascontiguousarray(resid, dtype=np.float16)
+    out = np.zeros((M, N), dtype=np.float16)
+    r = L.bert_hip_test_proj_ln(M, N, K, A.ctypes.data, wb.ctypes.data, wtype, bias.ctypes.data, resid.ctypes.data,
+                                gamma.ctypes.data, beta.ctypes.data, int(fused), out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_proj_ln failed: {r}")
     return out

@@ -68,10 +68,17 @@ BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const c
 /* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
  * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
  * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
- * 2 bias+residual.  impl: 0 mfma, 1 naive.  Output f16 bits.  Returns 0 on success.            */
+ * 2 bias+residual.  impl: 0 tiled MFMA kernel, 1 naive, 2 row-panel kernel (epilogue 0 only; -2 if the
+ * shape is not supported).  Output f16 bits.  Returns 0 on success.                             */
 BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
                                     int32_t wtype, const float *bias, const uint16_t *resid,
                                     int32_t epilogue, int32_t impl, uint16_t *C);
+
+/* out = LayerNorm(A W^T + bias + resid) * gamma + beta (reference bert.cpp:859-875).  fused: 1 = single
+ * row-panel kernel (-2 if unsupported), 0 = GEMM + LayerNorm kernels.                            */
+BERT_API int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype,
+                                       const float *bias, const uint16_t *resid, const float *gamma,
+                                       const float *beta, int32_t fused, uint16_t *out);
 
 /* Whole feed-forward block: out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * gamma + beta, y [M][H] f16 bits,
  * W1 [I][H] and W2 [H][I] in file layout of `wtype`.  fused: 1 = single fused kernel (returns -2 if the

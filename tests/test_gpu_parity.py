@@ -41,9 +41,10 @@ def _gelu(x):
     return 0.5 * x * (1 + np.tanh(0.7978845608028654 * x * (1 + 0.044715 * x * x)))
 
 
-@pytest.mark.parametrize("impl", [0, 1], ids=["mfma", "naive"])
+@pytest.mark.parametrize("impl", [0, 1, 2], ids=["mfma", "naive", "panel"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1", "f32"])
-@pytest.mark.parametrize("shape", [(200, 192, 128), (256, 384, 384), (130, 64, 64), (512, 1536, 384), (384, 384, 1536)])
+@pytest.mark.parametrize("shape", [(200, 192, 128), (256, 384, 384), (130, 64, 64), (512, 1536, 384), (384, 384, 1536),
+                                   (256, 1152, 384), (129, 2304, 768)])
 def test_gemm_kernel(impl, ftype, shape):
     M, N, K = shape
     rng = np.random.default_rng(hash((M, N, K, ftype)) % 2 ** 31)
@@ -56,13 +57,40 @@ def test_gemm_kernel(impl, ftype, shape):
     resid = rng.normal(0, 1, (M, N)).astype(np.float16)
     wb, wdeq = _weight_bytes(W, ftype)
     base = A.astype(np.float64) @ wdeq.astype(np.float64).T + bias
-    for epi in (0, 1, 2):
+    for epi in ((0,) if impl == 2 else (0, 1, 2)):
         want = base if epi == 0 else _gelu(base) if epi == 1 else base + resid.astype(np.float64)
-        got = pybert.test_gemm(A, wb, WT[ftype], N, bias, resid if epi == 2 else None, epi, impl).astype(np.float64)
+        try:
+            got = pybert.test_gemm(A, wb, WT[ftype], N, bias, resid if epi == 2 else None, epi, impl).astype(np.float64)
+        except RuntimeError as e:
+            if impl == 2 and "-2" in str(e):
+                pytest.skip("shape not handled by the row-panel kernel")
+            raise
         err = np.abs(got - want)
         tol = 2e-3 * np.abs(want) + 4e-3          # f16 output rounding + f16 weight rounding of the q4 dequant
         bad = err > tol
         assert not bad.any(), (ftype, shape, epi, impl, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5])
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["panel", "gemm+ln"])
+@pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1"])
+@pytest.mark.parametrize("M,N,K", [(200, 128, 64), (256, 384, 384), (130, 256, 512), (384, 384, 1536)])
+def test_proj_layernorm_kernel(fused, ftype, M, N, K):
+    """LayerNorm(A W^T + b + resid) * gamma + beta: row-panel kernel and GEMM + LayerNorm path vs numpy."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(0, 1, (M, K)).astype(np.float16)
+    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float32)
+    W[:, : K // 2] *= 1.5; W[: N // 3] += 0.02
+    bias = rng.normal(0, 0.5, N).astype(np.float32)
+    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
+    gamma = rng.normal(1, 0.2, N).astype(np.float32); beta = rng.normal(0, 0.3, N).astype(np.float32)
+    wb, wd = _weight_bytes(W, ftype)
+    got = pybert.test_proj_ln(A, wb, WT[ftype], N, bias, resid, gamma, beta, fused).astype(np.float64)
+    pre = A.astype(np.float64) @ wd.astype(np.float64).T + bias + resid.astype(np.float64)
+    mu = pre.mean(axis=1, keepdims=True)
+    want = (pre - mu) / np.sqrt(((pre - mu) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta
+    err = np.abs(got - want)
+    assert err.max() < 1.5e-2, (fused, ftype, M, N, K, float(err.max()), np.argwhere(err > 1.5e-2)[:5])
+    assert err.mean() < 1.5e-3
 
 
 @pytest.mark.parametrize("fused", [True, False], ids=["fused", "three-kernel"])
