@@ -56,6 +56,17 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
 
+    const int n_qblocks = (n + 31) / 32;
+    // Q fragments of this wave's first query block are requested before the K/V staging loads so that
+    // both HBM round trips overlap (B operand: lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +8]).
+    f16x8 qf[D / 16];
+    {
+        const int qrow = min(wave * 32 + l31, n - 1);
+        const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
+    }
+
     // ---- stage K (swizzled rows) and V^T (transposed) of this head; zero the padding
     constexpr int CPR = D / 8;                         // 16-byte chunks per row
     for (int idx = tid; idx < n_pad * CPR; idx += 256) {
@@ -74,14 +85,13 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
     __syncthreads();
 
     const float sc = 1.44269504088896340736f / __builtin_sqrtf((float)D);   // log2(e) / sqrt(d)
-    const int n_qblocks = (n + 31) / 32;
     for (int qb = wave; qb < n_qblocks; qb += 4) {
-        // Q fragments (B operand): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +8]
-        const int qrow = min(qb * 32 + l31, n - 1);
-        f16x8 qf[D / 16];
-        const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
+        if (qb != wave) {                              // later blocks (n > 128): fetch their Q fragments now
+            const int qrow = min(qb * 32 + l31, n - 1);
+            const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
 #pragma unroll
-        for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
+            for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
+        }
 
         f32x16 o[D / 32];
 #pragma unroll

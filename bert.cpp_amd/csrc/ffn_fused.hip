@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             if (WT == GW_F16) dma_tile8(a.w1 + (size_t)c * 128 * H + p * 64, loffH, dst + 16384, wave);
             else pend = q4_fetch<WT>(a.q1, a.s1, (size_t)c * KU + p, tid);
         } else {
-            const int n3 = (p - KU) >> 1, k2 = (p - KU) & 1;
+            const int k2 = (p - KU) / NT, n3 = (p - KU) - k2 * NT;      // k-half major: all of k2 = 0 first
             if (WT == GW_F16) dma_tile8(a.w2 + (size_t)n3 * 128 * I + c * 128 + k2 * 64, loffI, dst, wave);
             else pend = q4_fetch<WT>(a.q2, a.s2, (size_t)n3 * (I / 64) + 2 * c + k2, tid);
         }
@@ -97,9 +97,14 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     issue(0, 1, 1);                                  // its q4 part is committed in interval 0
 
     // per-lane LDS byte offsets of the MFMA fragments (swizzles are XORs, so one VGPR per k-step)
-    int aW[4], aY[4], aH[2][4];
+    // U phase: the wave's 32 MFMA rows are 16 features of each 64-feature half of the chunk
+    // (tile rows wq*16.. and 64 + wq*16..), so accumulator registers 0-7 belong to k-half 0 and 8-15 to
+    // k-half 1 of the D phase: the GELU of half 1 can run under the MFMAs of the first D tiles.
+    const int rowU = (l31 < 16 ? 0 : 48) + wq * 16 + l31;
+    int aW[4], aWU[4], aY[4], aH[2][4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
+        aWU[kk] = off64(rowU, kk * 2 + hi);
         aW[kk] = off64(wq * 32 + l31, kk * 2 + hi);
         aY[kk] = off64(wt * 64 + l31, kk * 2 + hi);
         aH[0][kk] = off_hc(wt * 64 + l31, kk * 2 + hi);
@@ -121,6 +126,27 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     // One chunk = TPC tiles; everything about a tile except the chunk index is a compile-time
     // constant of its position p, so the steady state is branch-free.  LAST = final chunk (its last
     // two tiles prefetch nothing and its last wait drains the DMA queue).
+    // bias + GELU + f16 of one k-half of the chunk's activation (accumulator registers 8*half .. 8*half+7 of
+    // both token fragments) into hc[token][feature]; the registers are re-zeroed for the next chunk
+    auto gelu_half = [&](int c, int half) {
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            const int g = half * 2 + gg;
+            const int fl = half * 64 + wq * 16 + gg * 8 + 4 * hi;          // feature within the chunk
+            const f32x4 bv = *(const f32x4 *)(cb1 + c * 128 + fl);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tok = wt * 64 + j * 32 + l31;
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (_Float16)gelu_fast(accU[j][4 * g + e] + bv[e]);
+                    accU[j][4 * g + e] = 0.f;
+                }
+                *(f16x4 *)(hc + off_hc(tok, fl >> 3) + (fl & 4) * 2) = o;
+            }
+        }
+    };
     int sbase = 0;                                   // ring slot of the chunk's first tile
     auto chunk = [&](auto last_tag, int c) {
         constexpr bool LAST = decltype(last_tag)::value;
@@ -143,12 +169,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             if (p < KU) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    wf[kk] = *(const f16x8 *)(ring + so + 16384 + aW[kk]);
+                    wf[kk] = *(const f16x8 *)(ring + so + 16384 + aWU[kk]);
                     a0[kk] = *(const f16x8 *)(ring + so + aY[kk]);
                     a1[kk] = *(const f16x8 *)(ring + so + aY[kk] + 32 * 128);
                 }
             } else {
-                const int k2 = (p - KU) & 1;
+                const int k2 = (p - KU) / NT;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     wf[kk] = *(const f16x8 *)(ring + so + aW[kk]);
@@ -172,34 +198,24 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
                     accU[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], accU[0], 0, 0, 0);
                     accU[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], accU[1], 0, 0, 0);
                 }
-                if (p == KU - 1) {
-                    // ---- chunk epilogue: bias + GELU, f16, into hc[token][feature] (read by the D tiles
-                    // after the next barrier; last read of the previous chunk's hc was >= KU barriers ago)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int fl = wq * 32 + 8 * g + 4 * hi;
-                        const f32x4 bv = *(const f32x4 *)(cb1 + c * 128 + fl);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int tok = wt * 64 + j * 32 + l31;
-                            f16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (_Float16)gelu_fast(accU[j][4 * g + e] + bv[e]);
-                            *(f16x4 *)(hc + off_hc(tok, fl >> 3) + (fl & 4) * 2) = o;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
-                }
+                if (p == KU - 1) gelu_half(c, 0);             // k-half 0 of hc is needed by the next tile
             } else {
                 // ---- D: acc2[n3] += W2 tile (features) x hc (tokens), k-half k2 of the chunk
-                const int n3 = (p - KU) >> 1;
+                const int n3 = (p - KU) % NT;
+                // k-half 1 of hc is first read NT tiles from now: its GELU overlaps this tile's MFMAs
+                if (p == KU) gelu_half(c, 1);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], acc2[n3][0], 0, 0, 0);
                     acc2[n3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], acc2[n3][1], 0, 0, 0);
+                }
+                if (p == KU) {
+                    // pin the interleave: one MFMA, then a slice of the GELU's VALU work in its shadow
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 24, 0);   // VALU (incl. transcendental)
+                    }
                 }
             }
         }
