@@ -67,13 +67,13 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir):
     d_out = torch.empty((B, H), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream(device)
     counts = [B] * world
-    gathered = {}
+    d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
 
     def step():
         model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, B * N, N, d_out.data_ptr(), stream.cuda_stream)
         if world > 1:
             # RCCL over xGMI: the path's one exchange step (bert.cpp_amd/dist.py), [world*B, H] on every rank
-            gathered["all"] = bdist.gather_embeddings(d_out, counts)
+            bdist.gather_embeddings(d_out, counts, out=d_all)
 
     for _ in range(args.warmup):
         step()

@@ -49,9 +49,11 @@ __device__ __forceinline__ void table_pair(const void *tab, int type, int H, int
 template <int NJ>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const void *type, const void *pos,
                                                        int table_type, const float *gamma, const float *beta,
-                                                       const int32_t *tokens, const int32_t *cu_seqlens,
-                                                       int n_sentences, int T, int H, int n_vocab, half_t *out) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                       const int32_t *__restrict__ tokens,
+                                                       const int32_t *__restrict__ cu_seqlens, int n_sentences,
+                                                       int T, int H, int n_vocab, half_t *__restrict__ out) {
+    // wave-uniform token index: the sentence search below then runs on scalar loads (constant cache)
+    const int t = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
     // sentence of token t: largest b with cu[b] <= t
     int lo = 0, hi = n_sentences;
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, co
     const float invn = 1.0f / (float)n;
     for (int e = 2 * lane; e < H; e += 128) {
         float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
         for (int t = wave; t < n; t += 4) {
             const f16x2 v = *(const f16x2 *)(x + (size_t)(tok0 + t) * H + e);
             a0 += (float)v[0] * invn; a1 += (float)v[1] * invn;

@@ -39,18 +39,25 @@ def shard_bounds(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
     return bounds
 
 
-def gather_embeddings(local, counts: Sequence[int], group=None):
+def gather_embeddings(local, counts: Sequence[int], group=None, out=None):
     """All-gather variable-sized shards of embeddings.
 
     local: torch tensor [counts[rank], H] on the rank's device; returns [sum(counts), H] in global
     sentence order on every rank.  One collective: shards are padded to the largest count so a
-    single all_gather_into_tensor moves everything."""
+    single all_gather_into_tensor moves everything.  `out` (optional, equal shards only) is a
+    preallocated [sum(counts), H] result buffer."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     assert len(counts) == world
     H = local.shape[1]
+    if min(counts) == max(counts) and local.shape[0] == counts[0] and counts[0] > 0:
+        # equal shards (fixed-length batches, the benchmark case): no padding, no copies
+        if out is None:
+            out = torch.empty((world * counts[0], H), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     mx = max(max(counts), 1)
     pad = torch.zeros((mx, H), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
