@@ -172,6 +172,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *a = getenv("BERT_HIP_ATTN")) e->attn_naive_ = strcmp(a, "naive") == 0;
     if (const char *f = getenv("BERT_HIP_FFN")) e->ffn_fused_ = strcmp(f, "unfused") != 0;
     if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -226,6 +227,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "ffn") ffn_fused_ = value != "unfused";
     else if (key == "panel") panel_ = value != "0";
+    else if (key == "layer_fused") layer_fused_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -315,6 +317,15 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
                 launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
         });
+        const bool ffn_ok = ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w);
+        if (layer_fused_ && panel_ && ffn_ok && L.o.mfma_ok && proj_ffn_fused_supported(L.o.w, L.ffi.w, L.ffo.w)) {
+            // out-projection + LN + FFN + LN of the same 128-token panels in one launch
+            timed("proj_ffn_fused", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
+                launch_proj_ffn_fused(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
+                                      L.ln_att_b.as<float>(), y, L.ffi_b.as<float>(), L.ffo_b.as<float>(),
+                                      L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
+            });
+        } else {
         if (panel_ && !gemm_naive_ && L.o.mfma_ok && panel_gemm_supported(L.o.w, true)) {
             timed("proj_ln", 2.0 * Td * L.o.w.N * L.o.w.K, s, [&] {
                 launch_proj_ln(L.o.w, ctx, L.o_b.as<float>(), x, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), y, t_pad, s);
@@ -323,7 +334,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
             timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
         }
-        if (ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w)) {
+        if (ffn_ok) {
             timed("ffn_fused", 4.0 * Td * H * I, s, [&] {
                 launch_ffn_fused(L.ffi.w, L.ffo.w, y, L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(),
                                  L.ln_out_b.as<float>(), x, t_pad, s);
@@ -332,6 +343,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
             gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
             timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+        }
         }
         tap(il + 1);
     }

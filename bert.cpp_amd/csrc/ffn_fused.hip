@@ -32,11 +32,19 @@ struct FfnArgs {
     const void *s1, *s2;   // q4 scale planes
     const float *b1, *b2, *gamma, *beta;
     half_t *out;           // [T_pad][H]
+    // optional leading phase (PROJ): y = LayerNorm(ctx Wo^T + bo + x) * g1 + beta1 is computed by this
+    // kernel first (written to `ybuf`, which then plays the role of `y`)
+    const half_t *ctx, *x;   // [T_pad][H] attention context, layer input (residual)
+    const half_t *wo;        // [H_pad][H] f16
+    const uint4 *qo;         // q4 planes of Wo
+    const void *so;
+    const float *bo, *g1, *beta1;
+    half_t *ybuf;            // [T_pad][H]
     int I;
     int skip;              // tuning aid (BERT_HIP_FFN_SKIP): 1 = no final epilogue, 2 = no main loop
 };
 
-template <int NT, int WT>
+template <int NT, int WT, bool PROJ>
 __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, KU = H / 64, TPC = KU + 2 * NT;
@@ -53,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     float *cb2 = cb1 + I, *cg = cb2 + H, *cbeta = cg + H;
     float *red = cbeta + H;                                   // [4 quarters][128 tokens]
 
-    const half_t *ybase = a.y + (size_t)m0 * H;
+    const half_t *ybase = (PROJ ? a.ybuf : a.y) + (size_t)m0 * H;
 
     // lane's byte offsets inside a [128 rows x 64 halfs] source tile with row stride H (y, W1) or I (W2);
     // the 16-byte chunk is pre-swizzled here and un-swizzled by the fragment reads (off64)
@@ -63,7 +71,6 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         const int r = (wave * 2 + i) * 8 + (lane >> 3);
         const int ch = (lane & 7) ^ ((r >> 1) & 7);
         loffH[i] = (unsigned)(r * H + ch * 8) * 2u;
-        loffI[i] = (unsigned)(r * I + ch * 8) * 2u;
     }
     // tile (chunk c, position p) -> ring slot `slot`; U tiles carry a y k-tile and a W1 k-tile, D tiles a W2
     // tile.  f16 weights travel by LDS-DMA like the activations; q4 weights are fetched into `pend` (two
@@ -89,26 +96,19 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         if (WT != GW_F16) q4_expand_to_lds<WT>(pend, ring + slot * FF_SLOT + (p < KU ? 16384 : 0), tid);
     };
 
-    // ---- prologue: constants into LDS, first two tiles in flight
+    // ---- prologue: constants into LDS (the first FFN tiles are requested further down)
     for (int i = tid; i < I; i += 512) cb1[i] = a.b1[i];
     for (int i = tid; i < H; i += 512) { cb2[i] = a.b2[i]; cg[i] = a.gamma[i]; cbeta[i] = a.beta[i]; }
-    issue(0, 0, 0);
-    commit(0, 0);
-    issue(0, 1, 1);                                  // its q4 part is committed in interval 0
 
     // per-lane LDS byte offsets of the MFMA fragments (swizzles are XORs, so one VGPR per k-step)
     // U phase: the wave's 32 MFMA rows are 16 features of each 64-feature half of the chunk
     // (tile rows wq*16.. and 64 + wq*16..), so accumulator registers 0-7 belong to k-half 0 and 8-15 to
     // k-half 1 of the D phase: the GELU of half 1 can run under the MFMAs of the first D tiles.
-    const int rowU = (l31 < 16 ? 0 : 48) + wq * 16 + l31;
-    int aW[4], aWU[4], aY[4], aH[2][4];
+    int aW[4], aWU[4], aY[4], aH[2][4];                // (aWU, aH, loffI are filled in after the PROJ phase)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        aWU[kk] = off64(rowU, kk * 2 + hi);
         aW[kk] = off64(wq * 32 + l31, kk * 2 + hi);
         aY[kk] = off64(wt * 64 + l31, kk * 2 + hi);
-        aH[0][kk] = off_hc(wt * 64 + l31, kk * 2 + hi);
-        aH[1][kk] = off_hc(wt * 64 + l31, 8 + kk * 2 + hi);
     }
 
     f32x16 acc2[NT][2], accU[2];
@@ -118,10 +118,85 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[n][j][r] = 0.f;
+
+    if (PROJ) {
+        // ---- leading phase: attention output projection + residual + LayerNorm for the same 128 tokens
+        // (reference bert.cpp:859-875), on the same ring: tiles (n3, k) = ctx k-tile + Wo tile.  Its result
+        // goes to global memory (the FFN streams it back k-tile by k-tile and needs it as residual).
+        float *cbo = red + 512, *cg1 = cbo + H, *cbeta1 = cg1 + H;
+        for (int i = tid; i < H; i += 512) { cbo[i] = a.bo[i]; cg1[i] = a.g1[i]; cbeta1[i] = a.beta1[i]; }
+        const half_t *cbase = a.ctx + (size_t)m0 * H;
+        auto issue_p = [&](int t, int slot) {
+            const int n3 = t / KU, k = t - n3 * KU;
+            char *dst = ring + slot * FF_SLOT;
+            dma_tile8(cbase + k * 64, loffH, dst, wave);
+            if (WT == GW_F16) dma_tile8(a.wo + (size_t)n3 * 128 * H + k * 64, loffH, dst + 16384, wave);
+            else pend = q4_fetch<WT>(a.qo, a.so, (size_t)n3 * KU + k, tid);
+        };
+        constexpr int PT = NT * KU;
+        issue_p(0, 0);
+        commit(0, 0);
+        issue_p(1, 1);
+        int slot = 0;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int n3 = 0; n3 < NT; ++n3) {
+            for (int k = 0; k < KU; ++k) {
+                const int t = n3 * KU + k;
+                if (t + 1 < PT) wait_vm_barrier<4>(); else wait_vm_barrier<0>();
+                if (t + 1 < PT) commit(0, slot == 2 ? 0 : slot + 1);
+                const char *sl = ring + slot * FF_SLOT;
+                f16x8 wf[4], a0[4], a1[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
+                for (int kk = 0; kk < 4; ++kk) {
+                    wf[kk] = *(const f16x8 *)(sl + 16384 + aW[kk]);
+                    a0[kk] = *(const f16x8 *)(sl + aY[kk]);
+                    a1[kk] = *(const f16x8 *)(sl + aY[kk] + 32 * 128);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < PT) issue_p(t + 2, slot == 0 ? 2 : slot - 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc2[n3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a0[kk], acc2[n3][0], 0, 0, 0);
+                    acc2[n3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[kk], a1[kk], acc2[n3][1], 0, 0, 0);
+                }
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+        }
+        ln_epilogue<NT>(acc2, cbo, cg1, cbeta1, red, a.x + (size_t)m0 * H, a.ybuf + (size_t)m0 * H, ring, tid, wt, wq, l31, hi);
+        // the y rows are re-read below by LDS-DMA: stores complete (write-through to L2), then everybody
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[n][j][r] = 0.f;
+    }
+    // per-lane values of the FFN phases only (computed here so they are not live across the PROJ phase)
+    {
+        const int rowU = (l31 < 16 ? 0 : 48) + wq * 16 + l31;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            aWU[kk] = off64(rowU, kk * 2 + hi);
+            aH[0][kk] = off_hc(wt * 64 + l31, kk * 2 + hi);
+            aH[1][kk] = off_hc(wt * 64 + l31, 8 + kk * 2 + hi);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = (wave * 2 + i) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            loffI[i] = (unsigned)(r * I + ch * 8) * 2u;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
+    }
+    // first two FFN tiles in flight
+    issue(0, 0, 0);
+    commit(0, 0);
+    issue(0, 1, 1);                                  // its q4 part is committed in interval 0
 
     // One chunk = TPC tiles; everything about a tile except the chunk index is a compile-time
     // constant of its position p, so the steady state is branch-free.  LAST = final chunk (its last
@@ -231,7 +306,11 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     if (a.skip & 1) { if (acc2[0][0][0] == 12345.f) a.out[0] = (_Float16)1; return; }
 
     // ---- final epilogue: + b2 + residual (the block input y), LayerNorm, gamma/beta, full-row stores
-    ln_epilogue<NT>(acc2, cb2, cg, cbeta, red, ybase, a.out + (size_t)m0 * H, ring, tid, wt, wq, l31, hi);
+    // (opaque copies of the lane ids: keeps the compiler from carrying the PROJ phase's epilogue addresses
+    // through the whole FFN loop just to reuse them here)
+    int tid_e = tid, l31_e = l31, hi_e = hi;
+    asm volatile("" : "+v"(tid_e), "+v"(l31_e), "+v"(hi_e));
+    ln_epilogue<NT>(acc2, cb2, cg, cbeta, red, ybase, a.out + (size_t)m0 * H, ring, tid_e, wt, wq, l31_e, hi_e);
 }
 
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
@@ -239,33 +318,59 @@ bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
     return W1.type == W2.type && W2.N == H && W2.K == I && H % 128 == 0 && H <= 384 && I % 128 == 0 && I <= 6144;
 }
 
-void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
-                      const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream) {
-    FfnArgs a;
-    a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.q1 = W1.qs; a.q2 = W2.qs; a.s1 = W1.sc; a.s2 = W2.sc; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+static void launch_ffn_impl(FfnArgs &a, const GemmWeight &W1, bool proj, int M_pad, hipStream_t stream) {
     a.I = W1.N;
     static int skip = -1;
     if (skip < 0) { const char *e = getenv("BERT_HIP_FFN_SKIP"); skip = e ? atoi(e) : 0; }
     a.skip = skip;
     const int H = W1.K;
-    const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512) * sizeof(float);
+    const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512 + (proj ? 3 * H : 0)) * sizeof(float);
     const int grid = M_pad / 128;
-    static bool configured[3][4] = {};
+    static bool configured[2][3][4] = {};
     auto go = [&](auto kernel, int nt) {
-        if (!configured[W1.type][nt]) {
+        if (!configured[proj][W1.type][nt]) {
             hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured[W1.type][nt] = true;
+            configured[proj][W1.type][nt] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
-#define FFN_NT(WTV)                                                                    \
+#define FFN_NT(WTV, PJ)                                                                \
     switch (H / 128) {                                                                  \
-        case 1: go(ffn_fused_kernel<1, WTV>, 1); break;                                 \
-        case 2: go(ffn_fused_kernel<2, WTV>, 2); break;                                 \
-        default: go(ffn_fused_kernel<3, WTV>, 3); break;                                \
+        case 1: go(ffn_fused_kernel<1, WTV, PJ>, 1); break;                             \
+        case 2: go(ffn_fused_kernel<2, WTV, PJ>, 2); break;                             \
+        default: go(ffn_fused_kernel<3, WTV, PJ>, 3); break;                            \
     }
-    if (W1.type == GW_F16) { FFN_NT(GW_F16) } else if (W1.type == GW_Q4_0) { FFN_NT(GW_Q4_0) } else { FFN_NT(GW_Q4_1) }
+    if (proj) {
+        if (W1.type == GW_F16) { FFN_NT(GW_F16, true) } else if (W1.type == GW_Q4_0) { FFN_NT(GW_Q4_0, true) } else { FFN_NT(GW_Q4_1, true) }
+    } else {
+        if (W1.type == GW_F16) { FFN_NT(GW_F16, false) } else if (W1.type == GW_Q4_0) { FFN_NT(GW_Q4_0, false) } else { FFN_NT(GW_Q4_1, false) }
+    }
 #undef FFN_NT
+}
+
+void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
+                      const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream) {
+    FfnArgs a = {};
+    a.y = y; a.w1 = W1.w16; a.w2 = W2.w16; a.q1 = W1.qs; a.q2 = W2.qs; a.s1 = W1.sc; a.s2 = W2.sc; a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+    launch_ffn_impl(a, W1, false, M_pad, stream);
+}
+
+// out-projection + residual + LayerNorm, then the whole FFN block, in ONE launch (same 128-token panels):
+//   y   = LayerNorm(ctx Wo^T + bo + x) * g1 + beta1        -> ybuf
+//   out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + beta2
+// out may alias x (every workgroup reads and later writes only its own 128 rows); it must not alias ctx / ybuf.
+bool proj_ffn_fused_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2) {
+    return ffn_fused_supported(W1, W2) && Wo.type == W1.type && Wo.N == W1.K && Wo.K == W1.K;
+}
+
+void launch_proj_ffn_fused(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx,
+                           const half_t *x, const float *bo, const float *g1, const float *beta1, half_t *ybuf,
+                           const float *b1, const float *b2, const float *g2, const float *beta2, half_t *out, int M_pad,
+                           hipStream_t stream) {
+    FfnArgs a = {};
+    a.y = ybuf; a.w1 = W1.w16; a.w2 = W2.w16; a.q1 = W1.qs; a.q2 = W2.qs; a.s1 = W1.sc; a.s2 = W2.sc; a.b1 = b1; a.b2 = b2; a.gamma = g2; a.beta = beta2; a.out = out;
+    a.ctx = ctx; a.x = x; a.wo = Wo.w16; a.qo = Wo.qs; a.so = Wo.sc; a.bo = bo; a.g1 = g1; a.beta1 = beta1; a.ybuf = ybuf;
+    launch_ffn_impl(a, W1, true, M_pad, stream);
 }
 
 }  // namespace bert_hip

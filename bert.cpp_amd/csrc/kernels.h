@@ -41,6 +41,11 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2);
 void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
                       const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream);
+bool proj_ffn_fused_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
+void launch_proj_ffn_fused(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx,
+                           const half_t *x, const float *bo, const float *g1, const float *beta1, half_t *ybuf,
+                           const float *b1, const float *b2, const float *g2, const float *beta2, half_t *out, int M_pad,
+                           hipStream_t stream);
 // Row-panel kernels (panel_gemm.hip): out = LayerNorm(A W^T + bias + resid) * gamma + beta, and C = A W^T + bias.
 bool panel_gemm_supported(const GemmWeight &W, bool with_ln);
 void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, const float *gamma,
