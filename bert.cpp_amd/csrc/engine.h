@@ -83,7 +83,7 @@ private:
     hipStream_t stream_ = nullptr;
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

@@ -173,6 +173,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *f = getenv("BERT_HIP_FFN")) e->ffn_fused_ = strcmp(f, "unfused") != 0;
     if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -228,6 +229,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "ffn") ffn_fused_ = value != "unfused";
     else if (key == "panel") panel_ = value != "0";
     else if (key == "layer_fused") layer_fused_ = value != "0";
+    else if (key == "qkv_att") qkv_att_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -309,6 +311,13 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const double att_flops = 4.0 * Td * max_len * H;
     for (int il = 0; il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
+        // one workgroup per sentence pays for 128 tokens whatever the length: worth it from ~48 tokens on average
+        if (qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && (long long)T >= 48ll * B &&
+            qkv_attention_supported(L.qkv.w, nh, dh, max_len)) {
+            timed("qkv_attention", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
+                launch_qkv_attention(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, nh, ctx, s);
+            });
+        } else {
         if (panel_ && !gemm_naive_ && L.qkv.mfma_ok && panel_gemm_supported(L.qkv.w, false))
             timed("panel_qkv", 2.0 * Td * L.qkv.w.N * L.qkv.w.K, s, [&] { launch_panel_store(L.qkv.w, x, L.qkv_b.as<float>(), qkv, t_pad, s); });
         else
@@ -317,6 +326,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
                 launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
         });
+        }
         const bool ffn_ok = ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w);
         if (layer_fused_ && panel_ && ffn_ok && L.o.mfma_ok && proj_ffn_fused_supported(L.o.w, L.ffi.w, L.ffo.w)) {
             // out-projection + LN + FFN + LN of the same 128-token panels in one launch

@@ -119,6 +119,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[n][j][r] = 0.f;
 
+    int tl = 1;
+    TL_STAMP(0);
     if (PROJ) {
         // ---- leading phase: attention output projection + residual + LayerNorm for the same 128 tokens
         // (reference bert.cpp:859-875), on the same ring: tiles (n3, k) = ctx k-tile + Wo tile.  Its result
@@ -143,6 +145,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             for (int k = 0; k < KU; ++k) {
                 const int t = n3 * KU + k;
                 if (t + 1 < PT) wait_vm_barrier<4>(); else wait_vm_barrier<0>();
+                TL_STAMP(tl++);
                 if (t + 1 < PT) commit(0, slot == 2 ? 0 : slot + 1);
                 const char *sl = ring + slot * FF_SLOT;
                 f16x8 wf[4], a0[4], a1[4];
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) accU[j][r] = 0.f;
     }
+    TL_STAMP(tl++);
     // first two FFN tiles in flight
     issue(0, 0, 0);
     commit(0, 0);
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
             if (LAST && p == TPC - 1) wait_vm_barrier<0>();
             else if (((p + 1) % TPC) < KU) wait_vm_barrier<4>();
             else wait_vm_barrier<2>();
+            if (c < 2 || LAST) TL_STAMP(tl++);
             // q4: the weights of tile +1 were fetched one interval ago; expand them into their (free) slot now
             if (WT != GW_F16 && !(LAST && p + 1 >= TPC)) {
                 int s1 = slot + 1;
@@ -310,7 +315,12 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
     // through the whole FFN loop just to reuse them here)
     int tid_e = tid, l31_e = l31, hi_e = hi;
     asm volatile("" : "+v"(tid_e), "+v"(l31_e), "+v"(hi_e));
+    TL_STAMP(tl++);
     ln_epilogue<NT>(acc2, cb2, cg, cbeta, red, ybase, a.out + (size_t)m0 * H, ring, tid_e, wt, wq, l31_e, hi_e);
+#ifdef BERT_HIP_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(tl++);
+#endif
 }
 
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
@@ -333,6 +343,7 @@ static void launch_ffn_impl(FfnArgs &a, const GemmWeight &W1, bool proj, int M_p
             configured[proj][W1.type][nt] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
+        TL_DUMP(grid >= 256, (proj ? (H / 128) * (H / 64) + 1 : 0) + 3 * (H / 64 + 2 * (H / 128)) + 4);
     };
 #define FFN_NT(WTV, PJ)                                                                \
     switch (H / 128) {                                                                  \

@@ -70,6 +70,12 @@ bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_s
 void launch_attention_naive(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
                             int max_len, half_t *out, hipStream_t stream);
 
+// Q|K|V projection + attention of whole sentences in one kernel (qkv_attention.hip): x [T_pad][H] -> ctx [T_pad][H].
+// One workgroup per sentence; f16 weights, d_head 32, H <= 384, every sentence <= 128 tokens.
+bool qkv_attention_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);
+void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
+                          int n_sentences, int n_head, half_t *out, hipStream_t stream);
+
 // mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
                            hipStream_t stream);

@@ -173,4 +173,40 @@ int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, 
     return 0;
 }
 
+int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
+                                    const uint16_t *x, const void *Wqkv, int32_t wtype, const float *bias, int32_t fused,
+                                    uint16_t *out) {
+    std::string err;
+    const int T = cu_seqlens[n_sentences], H = n_head * d_head;
+    const int T_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    int max_len = 0;
+    for (int b = 0; b < n_sentences; ++b) max_len = std::max(max_len, cu_seqlens[b + 1] - cu_seqlens[b]);
+    HostTensor t;
+    t.type = wtype; t.n_dims = 2; t.ne0 = H; t.ne1 = 3 * H; t.data = (const uint8_t *)Wqkv;
+    t.nbytes = wtype_row_bytes(wtype, H) * (size_t)3 * H;
+    GemmWeightStore ws;
+    if (!ws.build({&t}, false, err)) { fprintf(stderr, "bert_hip_test_qkv_attention: %s\n", err.c_str()); return -1; }
+    if (!ws.mfma_ok) return -2;
+    DevBuf dx, dqkv, dcu, db, dout;
+    if (!dx.alloc((size_t)T_pad * H * 2, err) || !dqkv.alloc((size_t)T_pad * 3 * H * 2, err) ||
+        !dcu.upload(cu_seqlens, (size_t)(n_sentences + 1) * 4, err) || !db.upload(bias, (size_t)3 * H * 4, err) ||
+        !dout.alloc((size_t)T_pad * H * 2, err)) {
+        fprintf(stderr, "bert_hip_test_qkv_attention: %s\n", err.c_str());
+        return -1;
+    }
+    CK(hipMemcpy(dx.p, x, (size_t)T * H * 2, hipMemcpyHostToDevice));
+    if (fused) {
+        if (!qkv_attention_supported(ws.w, n_head, d_head, max_len)) return -2;
+        launch_qkv_attention(ws.w, dx.as<half_t>(), db.as<float>(), dcu.as<int32_t>(), n_sentences, n_head, dout.as<half_t>(), nullptr);
+    } else {
+        launch_gemm_mfma(ws.w, dx.as<half_t>(), db.as<float>(), nullptr, dqkv.as<half_t>(), T_pad, EPI_BIAS, nullptr);
+        if (!launch_attention_mfma(dqkv.as<half_t>(), dcu.as<int32_t>(), n_sentences, n_head, d_head, max_len, dout.as<half_t>(), nullptr))
+            return -2;
+    }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)T * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -6,6 +6,8 @@
 #pragma once
 #include "kernels.h"
 
+#include <cstdio>
+
 namespace bert_hip {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -16,6 +18,33 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define AS_GLOBAL(p) ((const __attribute__((address_space(1))) void *)(p))
 #define AS_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 
+
+// Tuning aid, compiled in only with -DBERT_HIP_TIMELINE: thread 0 of every workgroup stamps the shader clock
+// (TL_STAMP) at the top of each interval; the launcher (TL_DUMP) prints the deltas of a few workgroups of its
+// 21st large launch to stderr.  Not part of the product build.
+#ifdef BERT_HIP_TIMELINE
+static __device__ unsigned long long g_timeline[1024 * 256];
+#define TL_STAMP(i) do { const int tl_i = (i); if (threadIdx.x == 0 && tl_i < 256) g_timeline[(blockIdx.x & 1023) * 256 + tl_i] = __builtin_readcyclecounter(); } while (0)
+#define TL_STAMP_AT(sel, i) do { const int tl_i = (i); if ((sel) && tl_i < 256) g_timeline[(blockIdx.x & 1023) * 256 + tl_i] = __builtin_readcyclecounter(); } while (0)
+#define TL_DUMP(cond, nstamps) do {                                                                          \
+    static int tl_shots = 0;                                                                                  \
+    if ((cond) && tl_shots++ == 20) {                                                                         \
+        (void)hipDeviceSynchronize();                                                                         \
+        static unsigned long long tl_h[1024 * 256];                                                           \
+        (void)hipMemcpyFromSymbol(tl_h, HIP_SYMBOL(g_timeline), sizeof(tl_h));                                \
+        const int tl_n = (nstamps) < 256 ? (nstamps) : 256;                                                   \
+        for (int b : {0, 1, 100, 255}) {                                                                      \
+            fprintf(stderr, "timeline wg %3d:", b);                                                           \
+            for (int i = 1; i < tl_n; ++i) fprintf(stderr, " %llu", tl_h[b * 256 + i] - tl_h[b * 256 + i - 1]); \
+            fprintf(stderr, "  total %llu\n", tl_h[b * 256 + tl_n - 1] - tl_h[b * 256]);                      \
+        }                                                                                                     \
+    }                                                                                                         \
+} while (0)
+#else
+#define TL_STAMP(i) do { } while (0)
+#define TL_STAMP_AT(sel, i) do { } while (0)
+#define TL_DUMP(cond, nstamps) do { } while (0)
+#endif
 
 constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
 constexpr int FF_RING = 3 * FF_SLOT;

@@ -24,7 +24,8 @@ BERT_HIP_H_SYMBOLS = [
     "bert_hip_load_tokenizer", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
-    "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_version",
+    "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
+    "bert_hip_version",
 ]
 
 
@@ -78,6 +79,8 @@ def lib() -> C.CDLL:
     L.bert_hip_test_ffn.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.bert_hip_test_attention.restype = i32
     L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
+    L.bert_hip_test_qkv_attention.restype = i32
+    L.bert_hip_test_qkv_attention.argtypes = [i32, i32p, i32, i32, vp, vp, i32, vp, i32, vp]
     L.bert_hip_version.restype = C.c_char_p
     _lib = L
     return L
@@ -230,6 +233,22 @@ def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head:
     r = L.bert_hip_test_attention(len(cu) - 1, _i32p(cu), n_head, d_head, qkv.ctypes.data, impl, out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_attention failed: {r}")
+    return out
+
+
+def test_qkv_attention(x: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head: int, W_bytes: np.ndarray, wtype: int,
+                       bias: np.ndarray, fused: bool) -> np.ndarray:
+    """x [T][H] f16, Wqkv [3H][H] in file layout of wtype, bias [3H] -> attention context [T][H] f16."""
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float16)
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    w = np.ascontiguousarray(W_bytes)
+    bias = np.ascontiguousarray(bias, dtype=np.float32)
+    out = np.zeros((x.shape[0], n_head * d_head), dtype=np.float16)
+    r = L.bert_hip_test_qkv_attention(len(cu) - 1, _i32p(cu), n_head, d_head, x.ctypes.data, w.ctypes.data, wtype,
+                                      bias.ctypes.data, 1 if fused else 0, out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_qkv_attention failed: {r}")
     return out
 
 

@@ -62,6 +62,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
  *   BERT_HIP_ATTN          "mfma" (default) | "naive"
+ *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernel for batches of long sentences
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load                            */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
@@ -90,6 +91,13 @@ BERT_API int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16
 /* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
 BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                          int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);
+
+/* Q|K|V projection + attention: x[T][H] f16 bits, Wqkv [3H][H] (Q rows, K rows, V rows) in file layout of `wtype`,
+ * bias[3H] -> ctx[T][H] f16 bits (reference bert.cpp:822-856).  fused: 1 = one kernel per sentence
+ * (qkv_attention.hip; -2 if the shape is not supported), 0 = GEMM kernel + attention kernel.       */
+BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
+                                             int32_t d_head, const uint16_t *x, const void *Wqkv, int32_t wtype,
+                                             const float *bias, int32_t fused, uint16_t *out);
 
 BERT_API const char *bert_hip_version(void);
 

@@ -158,6 +158,42 @@ def test_attention_kernel(impl, d_head, n_head, lens):
     assert err.max() < 6e-3, (impl, d_head, lens, float(err.max()), np.argwhere(err > 6e-3)[:5])
 
 
+@pytest.mark.parametrize("n_head", [2, 4, 12])
+@pytest.mark.parametrize("lens", [[128, 128, 128], [1, 2, 5, 31, 32, 33, 64, 100, 127, 128], [96, 97, 48]])
+def test_qkv_attention_fused_kernel(n_head, lens):
+    """Projection + attention of whole sentences in one kernel (qkv_attention.hip) against the two-kernel path
+    (same arithmetic: equal bits) and against a float64 reference of reference bert.cpp:822-856."""
+    d_head, H = 32, 32 * n_head
+    rng = np.random.default_rng(sum(lens) + n_head)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    x = rng.normal(0, 1, (T, H)).astype(np.float16)
+    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float16)
+    W[:H] *= 1.7
+    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
+    fused = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, True)
+    split = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, False)
+    assert np.array_equal(fused.view(np.uint16), split.view(np.uint16))
+    qkv = (x.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float16)
+    want = _attention_ref(qkv, cu, n_head, d_head)
+    err = np.abs(fused.astype(np.float64) - want)
+    assert err.max() < 6e-3, (n_head, lens, float(err.max()))
+
+
+def test_qkv_attention_fused_kernel_limits():
+    rng = np.random.default_rng(0)
+    H = 128
+    x = rng.normal(0, 1, (130, H)).astype(np.float16)
+    W = rng.normal(0, 0.1, (3 * H, H)).astype(np.float32)
+    bias = np.zeros(3 * H, np.float32)
+    cu = np.array([0, 130], np.int32)
+    with pytest.raises(RuntimeError, match="-2"):                      # longer than one workgroup's 128 tokens
+        pybert.test_qkv_attention(x, cu, 4, 32, W.astype(np.float16).view(np.uint8), 1, bias, True)
+    q = gf.quantize_q4_0(W)
+    with pytest.raises(RuntimeError, match="-2"):                      # f16 weights only
+        pybert.test_qkv_attention(x[:64], np.array([0, 64], np.int32), 4, 32, q.view(np.uint8), 2, bias, True)
+
+
 def test_attention_generic_head_dim():
     """d_head outside {32, 64} must route to the generic kernel (mfma entry reports unsupported)."""
     rng = np.random.default_rng(3)
@@ -251,12 +287,15 @@ def test_eval_matches_oracle_baseline_models(make_model, dims, ftype, n, lens):
 # ------------------------------------------------------------------------------------------------
 # API semantics
 # ------------------------------------------------------------------------------------------------
-def test_api_equivalences_and_batch_independence(make_model):
-    path, hp = make_model("tiny", "f16", 1)
+@pytest.mark.parametrize("dims,ftype", [("tiny", "f16"), ("tiny-h128", "f16"), ("tiny-h128", "q4_0"), ("tiny-d64", "q4_1")])
+def test_api_equivalences_and_batch_independence(make_model, dims, ftype):
+    path, hp = make_model(dims, ftype, 1)
     m = pybert.BertModel(path)
     rng = np.random.default_rng(0)
-    sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (7, 64, 1, 33, 20)]
+    sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (7, 64, 1, 33, 20, 64, 50, 3, 64, 11)]
     batch = m.eval_batch(sents)
+    for _ in range(3):                      # the same launch sequence gives the same bits every time
+        assert np.array_equal(m.eval_batch(sents), batch)
     single = np.stack([m.eval(s) for s in sents])
     cu = np.concatenate([[0], np.cumsum([len(s) for s in sents])]).astype(np.int32)
     packed = m.eval_packed(np.concatenate(sents), cu)
