@@ -67,12 +67,17 @@ __device__ __forceinline__ void wait_lgkm10(f16x8 &a0, f16x8 &a1, f16x8 &a2, f16
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
 }
 
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
-    (f(std::integral_constant<int, I>{}), ...);
+// Global loads the compiler does not track (its own wait for a tracked load would be vmcnt(0) and drain the
+// weight tiles in flight); retired by the counted wait of the k-tile loop, see wait_vm4_bias.
+__device__ __forceinline__ void gload_untracked(f32x4 &v, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p));
 }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+__device__ __forceinline__ void gload_untracked(float &v, const float *p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
+}
+__device__ __forceinline__ void wait_vm4_bias(f32x4 &b0, f32x4 &b1, f32x4 &b2, f32x4 &b3, float &bv) {
+    asm volatile("s_waitcnt vmcnt(4)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(bv) : : "memory");
+}
 
 }  // namespace
 
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
         TL_STAMP_AT(tl_sel, tl++);
         read_half(H0{}, H0{}, 0);                             // tile 0 landed before B0
         for (int h = 0; h <= n_head; ++h) {
-            f32x4 bqk[4];
+            f32x4 bqk[4] = {};
             float bvv = 0.f;
             if (h < n_head) {
 #pragma unroll
@@ -214,17 +219,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
                         // below so that the counted wait does not have to cover them
                         if (!SWAP) {
 #pragma unroll
-                            for (int gg = 0; gg < 4; ++gg) bqk[gg] = *(const f32x4 *)(bias_g + h * 32 + 8 * gg + 4 * hi);
+                            for (int gg = 0; gg < 4; ++gg) gload_untracked(bqk[gg], bias_g + h * 32 + 8 * gg + 4 * hi);
                         } else {
-                            bvv = bias_g[h * 32 + l31];
+                            gload_untracked(bvv, bias_g + h * 32 + l31);
                         }
                     }
                     issue(t + 2, slot == 0 ? 2 : slot - 1);
                     wait_half(H0{});
                     mma_half(H0{});
                     if (h < 3) TL_STAMP_AT(tl_sel, tl++);
-                    // tile t+1 has landed once at most the 4 pieces of tile t+2 are outstanding
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    // tile t+1 has landed once at most the 4 pieces of tile t+2 are outstanding (so have the older
+                    // bias loads: the last tile's wait hands them to the epilogue)
+                    if (kt == KT - 1) wait_vm4_bias(bqk[0], bqk[1], bqk[2], bqk[3], bvv);
+                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                     read_half(std::integral_constant<int, (kt + 1) % KT>{}, H0{}, so1);
                     wait_half(H1{});
                     mma_half(H1{});

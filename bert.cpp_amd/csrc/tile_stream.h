@@ -7,6 +7,8 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <type_traits>
+#include <utility>
 
 namespace bert_hip {
 
@@ -14,6 +16,14 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 #define AS_GLOBAL(p) ((const __attribute__((address_space(1))) void *)(p))
 #define AS_LDS(p) ((__attribute__((address_space(3))) void *)(p))

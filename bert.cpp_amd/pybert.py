@@ -13,7 +13,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbert.so")
+LIB_PATH = os.environ.get("BERT_HIP_LIB") or os.path.join(_HERE, "libbert.so")   # BERT_HIP_LIB: tuning builds
 
 # every symbol include/bert.h and include/bert_hip.h declare
 BERT_H_SYMBOLS = [
