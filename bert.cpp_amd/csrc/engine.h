@@ -31,10 +31,11 @@ struct DevBuf {
 // Owns the HBM image of one weight matrix in the layouts kernels.h describes.
 struct GemmWeightStore {
     GemmWeight w;
-    DevBuf w16, qs, sc, naive16;
+    DevBuf w16, w16p, qs, sc, naive16;
     bool mfma_ok = false;
     // rows: list of (file tensor) stacked along N (one entry, or q|k|v).  All share type and K.
-    bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err);
+    // want_kperm: also build GemmWeight::w16p (f16 weights only)
+    bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm = false);
 };
 
 struct LayerWeights {
@@ -83,7 +84,7 @@ private:
     hipStream_t stream_ = nullptr;
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, tail_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

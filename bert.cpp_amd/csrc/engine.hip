@@ -82,7 +82,7 @@ void row_to_f16(const HostTensor &t, int64_t r, _Float16 *dst) {
 
 }  // namespace
 
-bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err) {
+bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm) {
     const int64_t K = rows[0]->ne0;
     const int ftype = rows[0]->type;
     int64_t N = 0;
@@ -104,6 +104,17 @@ bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool wa
         for (int64_t n = 0; n < N; ++n) { const HostTensor *t; int64_t r; src_row(n, t, r); row_to_f16(*t, r, img.data() + (size_t)n * K); }
         if (!w16.upload(img.data(), img.size() * 2, err)) return false;
         w.w16 = w16.as<half_t>();
+        if (want_kperm && K % 16 == 0) {
+            std::vector<_Float16> pimg(img.size());
+            for (size_t base = 0; base < img.size(); base += 16)
+                for (int j = 0; j < 16; ++j) {
+                    // stored position j of a group <- k offset: [0-3, 8-11, 4-7, 12-15]
+                    const int src = (j & 3) + ((j >> 2) & 1) * 8 + (j >> 3) * 4;
+                    pimg[base + j] = img[base + src];
+                }
+            if (!w16p.upload(pimg.data(), pimg.size() * 2, err)) return false;
+            w.w16p = w16p.as<half_t>();
+        }
     } else if (mfma_ok) {
         w.type = ftype == W_Q4_0 ? GW_Q4_0 : GW_Q4_1;
         const int bs = ftype == W_Q4_0 ? 18 : 20, scb = ftype == W_Q4_0 ? 2 : 4;
@@ -174,6 +185,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -198,9 +210,9 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
         ok = ok && upload_f32(L->o_b, T(p + "attention.output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_att_w, T(p + "attention.output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_att_b, T(p + "attention.output.LayerNorm.bias"), err);
-        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err);
+        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, true);
         ok = ok && upload_f32(L->ffi_b, T(p + "intermediate.dense.bias"), err);
-        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err);
+        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, true);
         ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
@@ -230,6 +242,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "panel") panel_ = value != "0";
     else if (key == "layer_fused") layer_fused_ = value != "0";
     else if (key == "qkv_att") qkv_att_ = value != "0";
+    else if (key == "tail") tail_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -328,7 +341,14 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         });
         }
         const bool ffn_ok = ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w);
-        if (layer_fused_ && panel_ && ffn_ok && L.o.mfma_ok && proj_ffn_fused_supported(L.o.w, L.ffi.w, L.ffo.w)) {
+        if (tail_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail_supported(L.o.w, L.ffi.w, L.ffo.w)) {
+            // token-owning waves: out-projection + LN + FFN + LN, y and the intermediate never leave the registers
+            timed("layer_tail", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
+                launch_layer_tail(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
+                                  L.ln_att_b.as<float>(), L.ffi_b.as<float>(), L.ffo_b.as<float>(),
+                                  L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
+            });
+        } else if (layer_fused_ && panel_ && ffn_ok && L.o.mfma_ok && proj_ffn_fused_supported(L.o.w, L.ffi.w, L.ffo.w)) {
             // out-projection + LN + FFN + LN of the same 128-token panels in one launch
             timed("proj_ffn_fused", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
                 launch_proj_ffn_fused(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),

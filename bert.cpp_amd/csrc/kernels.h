@@ -31,6 +31,9 @@ struct GemmWeight {
     const uint4 *qs = nullptr;
     const void *sc = nullptr;
     const half_t *naive16 = nullptr;
+    // optional second f16 image whose k order inside every group of 16 is [0-3, 8-11, 4-7, 12-15]: a 16-byte half
+    // of a group then holds the k's one lane of an MFMA accumulator column owns (layer_tail.hip)
+    const half_t *w16p = nullptr;
 };
 
 // C[t][n] = epi( sum_k A[t][k] * W[n][k] + bias[n] (+ resid[t][n]) ), t < M_pad (multiple of 128)
@@ -46,6 +49,11 @@ void launch_proj_ffn_fused(const GemmWeight &Wo, const GemmWeight &W1, const Gem
                            const half_t *x, const float *bo, const float *g1, const float *beta1, half_t *ybuf,
                            const float *b1, const float *b2, const float *g2, const float *beta2, half_t *out, int M_pad,
                            hipStream_t stream);
+// Out-projection + LN + FFN + LN with token-owning waves (layer_tail.hip); f16 weights, W1 / W2 need w16p.
+bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
+void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
+                       const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
+                       const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
 // Row-panel kernels (panel_gemm.hip): out = LayerNorm(A W^T + bias + resid) * gamma + beta, and C = A W^T + bias.
 bool panel_gemm_supported(const GemmWeight &W, bool with_ln);
 void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, const float *gamma,

@@ -1,0 +1,553 @@
+// layer_tail.hip — everything of an encoder layer after the attention, in ONE kernel in which every wave OWNS its
+// tokens (gfx950, f16 weights):
+//     y     = LayerNorm(ctx Wo^T + bo + x) * g1 + be1                     (reference bert.cpp:859-875)
+//     x_out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2       (reference bert.cpp:878-901)
+//
+// Workgroup = 128 tokens = 4 waves x 32 tokens, one wave per SIMD with the whole 512-register budget.  A wave
+// computes ALL output features of its 32 tokens, so
+//   * the MFMA B operand (tokens) never goes through LDS between the GEMMs: the LayerNorm'ed y and the GELU'ed
+//     intermediate chunk are produced in the accumulator layout (lane = token, 4-feature runs) and, converted to
+//     f16, ARE the next GEMM's B fragments — the weights are stored with the matching order inside every group
+//     of 16 k (GemmWeight::w16p), so no shuffle is needed;
+//   * both LayerNorms are wave-local (row statistics = the lane's registers + one cross-half shuffle), y is
+//     never written to HBM, and there is no barrier between a GEMM and its epilogue;
+//   * the GELU of chunk c runs as VALU filler under the MFMAs of the NEXT chunk's up-projection (two sets of
+//     up-projection accumulators), so the matrix pipe does not wait for it.
+// The intermediate dimension is processed in chunks of 64 features (up-projection tile = [64 rows x 128 k], down-
+// projection tile = [128 rows x 64 k]): small enough for two sets of up-projection accumulators next to the 192
+// output accumulators without a single spill — a scratch reload inside the tile loop would queue behind the
+// weight tiles in flight (vmcnt is in-order) and serialise the whole pipeline.
+// Only the weight tiles (16 KiB) are shared: they stream through a 3-slot LDS ring by LDS-DMA,
+// two tiles ahead, one barrier per tile.  Each wave hides its own LDS latency (tile_stream.h, hand-issued reads):
+// the fragments of a tile are read in two halves, and the second half's MFMAs run after the next barrier, under
+// the reads of the next tile.
+//
+// LDS: 4 x 24 KiB wave-private staging (x rows -> y fragments -> output rows), 48 KiB ring, biases / LayerNorm
+// parameters.  Registers (H = 384): 192 output accumulators + 2 x 32 up-projection accumulators + 16 (GELU'ed
+// chunk) + 64 weight fragments + 32 y fragments.
+#include "tile_stream.h"
+
+namespace bert_hip {
+
+namespace {
+
+constexpr int LT_TILE = 16384;
+
+struct TailArgs {
+    const half_t *ctx, *x;            // [T_pad][H]
+    const half_t *wo;                 // [H_pad][H] f16
+    const half_t *w1p;                // [I_pad][H] f16, k order permuted inside groups of 16 (GemmWeight::w16p)
+    const half_t *w2p;                // [H_pad][I] f16, same
+    const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
+    half_t *out;                      // [T_pad][H]
+    int I;
+};
+
+// tile kinds of the stream
+constexpr int K_NONE = 0, K_PROJ = 1, K_UP = 2, K_DOWN = 3;
+template <int KIND, int I0, int I1>
+struct TileDesc {
+    static constexpr int kind = KIND, i0 = I0, i1 = I1;
+};
+using NoTile = TileDesc<K_NONE, 0, 0>;
+
+__device__ __forceinline__ void wait_lgkm8(f16x8 (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(8)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory");
+}
+__device__ __forceinline__ void wait_lgkm12(f16x8 (&f)[8], f16x8 (&y)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(12)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : : "memory");
+}
+// tile barrier: this wave's share of the next tile has landed (all but the newest VM pieces), every hand-issued
+// read has returned (the second-half fragments are named: their MFMAs run after the barrier)
+template <int VM>
+__device__ __forceinline__ void tile_barrier(f16x8 (&f)[8], f16x8 (&y)[4]) {
+    asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
+                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "n"(VM) : "memory");
+}
+
+}  // namespace
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int H = 128 * NT, KU = 2 * NT, NB = 4 * NT, NQ = 8 * NT;
+    constexpr int S_BYTES = 64 * H;                           // 32 tokens x H halfs per wave
+    const int I = a.I, NC = I / 64;                           // chunks of 64 intermediate features
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int tok_w = blockIdx.x * 128 + wave * 32;           // first token of this wave
+
+    char *S = smem + wave * S_BYTES;
+    char *ring = smem + 4 * S_BYTES;
+    float *cbo = (float *)(ring + 3 * LT_TILE);
+    float *cg1 = cbo + H, *cbe1 = cg1 + H, *cb2 = cbe1 + H, *cg2 = cb2 + H, *cbe2 = cg2 + H, *cb1 = cbe2 + H;
+
+    // ---- prologue: parameters -> LDS; this wave's x rows -> S (16-byte unit of (token, 8-feature chunk c) at
+    // position c*32 + ((token + c) & 31): conflict-free 8-byte reads in the accumulator layout)
+    for (int i = tid; i < H; i += 256) {
+        cbo[i] = a.bo[i]; cg1[i] = a.g1[i]; cbe1[i] = a.be1[i]; cb2[i] = a.b2[i]; cg2[i] = a.g2[i]; cbe2[i] = a.be2[i];
+    }
+    for (int i = tid; i < I; i += 256) cb1[i] = a.b1[i];
+    {
+        const half_t *xw = a.x + (size_t)tok_w * H;
+#pragma unroll
+        for (int p = 0; p < H / 16; ++p) {
+            const int u = p * 64 + lane, c = u >> 5, tok = ((u & 31) - c) & 31;
+            __builtin_amdgcn_global_load_lds(AS_GLOBAL(xw + (size_t)tok * H + c * 8), AS_LDS(S + p * 1024), 16, 0, 0);
+        }
+    }
+    // attention context of this wave's tokens as B fragments, straight into registers (k order as stored)
+    f16x8 bf[NQ];
+    {
+        const half_t *cw = a.ctx + (size_t)(tok_w + l31) * H + 8 * hi;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) bf[q] = *(const f16x8 *)(cw + 16 * q);
+    }
+
+    // ---- weight-tile stream: [128 rows x 64 k] tiles, 16 pieces of 1 KiB, 4 per wave
+    // ([64 rows x 128 k] for the up-projection: 256-byte rows, 16-byte chunk ^ (row & 15), 4 rows per piece).
+    // The feed-forward's lane offsets and addresses are (re)computed after the out-projection from an opaque copy of
+    // the lane id: values that live across the out-projection (where the 96 context registers are alive) get
+    // spilled for their whole life, and a reload inside the tile loop queues behind the DMA in flight.
+    // Lane offsets of the DMA pieces, kept in few registers: piece i of this wave covers rows (wave*4+i)*8.. of a
+    // [128 x 64] tile; the row part of i goes into the scalar base, the swizzle alternates between two values
+    // (even / odd i).  For the [64 x 128] up-projection tile (rows (wave*4+i)*4..) the swizzle of piece i is the one
+    // of piece 0 with i XORed into bits 6..7.
+    unsigned offHe, offHo, offIe, offIo, offUb, offUx;
+    auto lane_offsets = [&](int ln) __attribute__((always_inline)) {
+        const int ch0 = (ln & 7) ^ (ln >> 4), row = wave * 32 + (ln >> 3);
+        offHe = (unsigned)(row * H * 2 + ch0 * 16);
+        offHo = (unsigned)(row * H * 2 + (ch0 ^ 4) * 16);
+        offIe = (unsigned)(row * I * 2 + ch0 * 16);
+        offIo = (unsigned)(row * I * 2 + (ch0 ^ 4) * 16);
+        offUb = (unsigned)((wave * 16 + (ln >> 4)) * H * 2);
+        offUx = (unsigned)(((ln & 15) ^ (ln >> 4)) * 16);
+    };
+    lane_offsets(lane);
+    const half_t *const wo = a.wo, *const w1p = a.w1p, *const w2p = a.w2p;     // (locals: keeps the argument struct out of scratch)
+    auto dma128 = [&](const half_t *base, unsigned oe, unsigned oo, int row_bytes, int slot) __attribute__((always_inline)) {
+        char *dst = ring + slot * LT_TILE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 8 * row_bytes + ((i & 1) ? oo : oe)),
+                                             AS_LDS(dst + i * 1024), 16, 0, 0);
+    };
+    auto dma_proj = [&](int n3, int kt, int slot) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offHe, offHo, H * 2, slot); };
+    auto dma_down = [&](int c, int n3, int slot) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offIe, offIo, I * 2, slot); };
+    auto dma_up = [&](int c, int j, int slot) __attribute__((always_inline)) {
+        const half_t *base = w1p + (size_t)c * 64 * H + j * 128;
+        char *dst = ring + slot * LT_TILE + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 4 * H * 2 + (offUb + (offUx ^ (unsigned)(i << 6)))),
+                                             AS_LDS(dst + i * 1024), 16, 0, 0);
+    };
+
+    // ---- per-lane LDS addresses
+    // weight fragment of k-step kk: the swizzles are XORs of the 16-byte chunk index 2*kk + hi, so the address of
+    // k-step kk is the address of k-step 0 with kk XORed into bits 5.. (one register per tile shape instead of 4 / 8)
+    unsigned aA0 = lds_addr(ring) + off64(l31, hi);                                   // [128 x 64]: + ob * 4 KiB + slot * 16 KiB
+    unsigned aU0 = lds_addr(ring) + l31 * 256 + ((hi ^ (l31 & 15)) << 4);            // [64 x 128]: + fb * 8 KiB + slot * 16 KiB
+    unsigned aY = lds_addr(S) + lane * 16;                    // y fragment q at + q * 1 KiB
+
+    f32x16 acc2[NB], accU[2];
+    f16x8 g[2][4];                                            // GELU'ed chunks (two in flight) as B fragments
+    f16x8 F[2][8], Y[2][4];                                   // weight fragments [half][...], y fragments [half][i]
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) F[hh][j] = (f16x8)(_Float16)0;
+        Y[hh][0] = Y[hh][1] = Y[hh][2] = Y[hh][3] = (f16x8)(_Float16)0;
+    }
+
+    // fragment reads of one half of the tile in ring slot `slot_off`.  [128 x 64] tiles: k-steps 2*half + i, 4 row
+    // blocks, F[half][ob*2 + i].  Up-projection [64 x 128] tiles: k-steps 4*half + i, 2 row blocks, F[half][fb*4 + i],
+    // plus the 4 y fragments of those k-steps.
+    auto read_half = [&](auto desc, auto half_tag, unsigned slot_off) __attribute__((always_inline)) {
+        using D = decltype(desc);
+        constexpr int half = decltype(half_tag)::value;
+        if constexpr (D::kind == K_UP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ad = (aU0 ^ (unsigned)((half * 4 + i) << 5)) + slot_off;
+                F[half][0 + i] = lds_read_b128_u<0>(ad);
+                F[half][4 + i] = lds_read_b128_u<8192>(ad);
+            }
+            Y[half][0] = lds_read_b128_u<(8 * D::i1 + 4 * half + 0) * 1024>(aY);
+            Y[half][1] = lds_read_b128_u<(8 * D::i1 + 4 * half + 1) * 1024>(aY);
+            Y[half][2] = lds_read_b128_u<(8 * D::i1 + 4 * half + 2) * 1024>(aY);
+            Y[half][3] = lds_read_b128_u<(8 * D::i1 + 4 * half + 3) * 1024>(aY);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned ad = (aA0 ^ (unsigned)((half * 2 + i) << 5)) + slot_off;
+                F[half][0 + i] = lds_read_b128_u<0>(ad);
+                F[half][2 + i] = lds_read_b128_u<4096>(ad);
+                F[half][4 + i] = lds_read_b128_u<8192>(ad);
+                F[half][6 + i] = lds_read_b128_u<12288>(ad);
+            }
+        }
+    };
+    // the 8 MFMAs of one half of a tile.  PROJ <n3, kt>: acc2[n3*4+ob] += Wo x ctx;  UP <0, j>: accU += W1 x y;
+    // DOWN <gpar, n3>: acc2[n3*4+ob] += W2 x gelu chunk in g[gpar]
+    auto mma_half = [&](auto desc, auto half_tag, auto &&fill) __attribute__((always_inline)) {
+        using D = decltype(desc);
+        constexpr int half = decltype(half_tag)::value;
+        // fill(k): VALU filler issued behind the k-th MFMA of the half (k = 0..7), in program order
+        if constexpr (D::kind == K_UP) {
+            static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_tag)::value, i = k >> 1, fb = k & 1;
+                accU[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][fb * 4 + i], Y[half][i], accU[fb], 0, 0, 0);
+                fill(k_tag);
+            });
+        } else {
+            static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
+                constexpr int k = decltype(k_tag)::value, i = k >> 2, ob = k & 3;
+                if constexpr (D::kind == K_PROJ)
+                    acc2[D::i0 * 4 + ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][ob * 2 + i], bf[4 * D::i1 + 2 * half + i], acc2[D::i0 * 4 + ob], 0, 0, 0);
+                else
+                    acc2[D::i1 * 4 + ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][ob * 2 + i], g[D::i0][2 * half + i], acc2[D::i1 * 4 + ob], 0, 0, 0);
+                fill(k_tag);
+            });
+        }
+    };
+
+    int slot = 0;                                             // ring slot of the current tile
+    int tl = 1;
+    TL_STAMP(0);
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    // One interval = one tile.  On entry the tile is complete in LDS for every wave.  `prev` = the tile whose second
+    // half is still owed (NoTile after a drain), `prefetch(slot)` requests tile +2, `filler(group, k)` is VALU work
+    // issued behind the k-th MFMA of the owed half (group 0) / of this tile's first half (group 1), VM = DMA pieces of this wave that may stay in flight at the closing barrier.
+    auto interval = [&](auto cur, auto prev, auto vm_tag, auto &&prefetch, auto &&filler) __attribute__((always_inline)) {
+        using C = decltype(cur);
+        using P = decltype(prev);
+        constexpr int VM = decltype(vm_tag)::value;
+        const unsigned so = (unsigned)slot * LT_TILE;
+        TL_STAMP(tl++);
+        prefetch(slot == 0 ? 2 : slot - 1);                   // slot + 2 (mod 3): read one tile ago, free since the barrier
+        read_half(cur, H0{}, so);
+        if constexpr (P::kind != K_NONE) mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) { filler(H0{}, k); });
+        read_half(cur, H1{}, so);
+        if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
+        mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) { filler(H1{}, k); });
+        tile_barrier<VM>(F[1], Y[1]);
+        slot = slot == 2 ? 0 : slot + 1;
+    };
+    auto nothing = [](auto, auto) __attribute__((always_inline)) {};
+    auto drain = [&](auto prev) __attribute__((always_inline)) { mma_half(prev, H1{}, [](auto) __attribute__((always_inline)) {}); };
+    using VM4 = std::integral_constant<int, 4>;
+    using VM0 = std::integral_constant<int, 0>;
+
+    // GELU of fragment j (features 32*(j>>1) + 16*(j&1) .. +16 of chunk c) of the up-projection accumulators into
+    // g[par], in four steps of two elements so that it can be spread behind the MFMAs of an interval (a wave's VALU work
+    // only overlaps its own MFMAs if it is issued between them)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    auto gelu_pair = [&](auto par_tag, auto j_tag, auto p_tag, int c) __attribute__((always_inline)) {
+        constexpr int par = decltype(par_tag)::value, j = decltype(j_tag)::value, fb = j >> 1, s = j & 1;
+        constexpr int p = decltype(p_tag)::value;             // elements 2p, 2p+1 of the fragment = registers 8s + 2p, +1
+        // their features: 32fb + 16s + 4hi + {2p, 2p+1} (p < 2) or + 8 + {2p-4, 2p-3}
+        const f32x2 b = *(const f32x2 *)(cb1 + c * 64 + 32 * fb + 16 * s + 4 * hi + (p < 2 ? 2 * p : 4 + 2 * p));
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            constexpr int e0 = 2 * p;
+            const float xv = accU[fb][8 * s + e0 + t] + b[t];
+#if defined(LT_EXP) && LT_EXP == 1
+            g[par][j][e0 + t] = (_Float16)(0.5f * xv);
+#else
+            g[par][j][e0 + t] = (_Float16)gelu_fast(xv);
+#endif
+            accU[fb][8 * s + e0 + t] = 0.f;
+        }
+    };
+
+    // ================================ out-projection ================================
+    dma_proj(0, 0, 0);
+    if (NT * KU > 1) dma_proj(KU > 1 ? 0 : 1, KU > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // x rows, ctx fragments, tiles 0 and 1
+    static_for<NT * KU>([&](auto t_tag) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_tag)::value, n3 = t / KU, kt = t % KU;
+        using Cur = TileDesc<K_PROJ, n3, kt>;
+        using Prev = std::conditional_t<t == 0, NoTile, TileDesc<K_PROJ, (t - 1) / KU, (t - 1) % KU>>;
+        // tile t+2: still out-projection, or the first up-projection tiles of chunk 0
+        auto pf = [&](int s2) __attribute__((always_inline)) {
+            constexpr int t2 = t + 2;
+            if constexpr (t2 < NT * KU) dma_proj(t2 / KU, t2 % KU, s2);
+            else dma_up(0, t2 - NT * KU, s2);                 // up-projection tiles 0, 1 of chunk 0 (NT >= 2), see below
+        };
+        interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+    });
+    drain(TileDesc<K_PROJ, NT - 1, KU - 1>{});
+
+    // ================================ LayerNorm 1 (wave-local) -> y fragments in S ================================
+    // (the epilogues use opaque copies of the lane ids: otherwise their address arithmetic is computed at kernel start
+    // and carried through the tile loop in registers the loop needs)
+    {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int l31 = lane_e & 31, hi = lane_e >> 5, lane = lane_e;
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int c = 4 * n + gq, f0 = 32 * n + 8 * gq + 4 * hi;
+                const f32x4 bv = *(const f32x4 *)(cbo + f0);
+                const f16x4 xv = *(const f16x4 *)(S + (c * 32 + ((l31 + c) & 31)) * 16 + hi * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = acc2[n][4 * gq + e] + bv[e] + (float)xv[e];
+                    acc2[n][4 * gq + e] = v;
+                    sum += v;
+                }
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / H);
+        float sq = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc2[n][r] - mean;
+                acc2[n][r] = d;
+                sq += d * d;
+            }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / H) + 1e-5f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every x read of the wave is done before S is rewritten
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    o[e] = (_Float16)(cg1[f] * (acc2[n][r] * rstd) + cbe1[f]);
+                    acc2[n][r] = 0.f;
+                }
+                *(f16x8 *)(S + (2 * n + s) * 1024 + lane * 16) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // y is read back by hand-issued reads of this wave
+    }
+
+    // ================================ feed-forward ================================
+    auto refresh_lane_values = [&]() __attribute__((always_inline)) {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        lane_offsets(lane_e);
+        const int l31e = lane_e & 31, hie = lane_e >> 5;
+        aA0 = lds_addr(ring) + off64(l31e, hie);
+        aU0 = lds_addr(ring) + l31e * 256 + ((hie ^ (l31e & 15)) << 4);
+        aY = lds_addr(S) + lane_e * 16;
+    };
+    refresh_lane_values();
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accU[fb][r] = 0.f;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[pp][j] = (f16x8)(_Float16)0;
+    // stream order (NT tiles per stage):
+    //     UP(0) | gelu(0) | UP(1) | DOWN(0)+gelu(1) | UP(2) | DOWN(1)+gelu(2) | ... | UP(NC-1) | DOWN(NC-2)+gelu(NC-1) | DOWN(NC-1)
+    // the GELU of chunk c+1 is VALU filler behind the MFMAs of DOWN(c); only gelu(0) is exposed.  One set of up-
+    // projection accumulators, two GELU'ed chunks (g[c & 1]).  NT >= 2 and NC >= 2.
+    // ---- UP(0)  (its first two tiles were requested by the last out-projection intervals)
+    static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
+        constexpr int j = decltype(j_tag)::value;
+        using Cur = TileDesc<K_UP, 0, j>;
+        using Prev = std::conditional_t<j == 0, NoTile, TileDesc<K_UP, 0, j - 1>>;
+        auto pf = [&](int s2) __attribute__((always_inline)) {
+            constexpr int j2 = j + 2;
+            if constexpr (j2 < NT) dma_up(0, j2, s2); else dma_up(1, j2 - NT, s2);
+        };
+        interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+    });
+    drain(TileDesc<K_UP, 0, NT - 1>{});
+    static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
+        static_for<4>([&](auto p_tag) __attribute__((always_inline)) { gelu_pair(H0{}, j_tag, p_tag, 0); });
+    });
+
+    // ---- step c: UP(c+1), then DOWN(c) with gelu(c+1) as filler.  GP = c & 1 (g buffer of chunk c).
+    auto step = [&](auto gp_tag, auto first_tag, int c) __attribute__((always_inline)) {
+        constexpr int GP = decltype(gp_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
+            constexpr int j = decltype(j_tag)::value;
+            using Cur = TileDesc<K_UP, 0, j>;
+            // owed on entry: nothing after the exposed gelu(0), else the last tile of DOWN(c-1)
+            using Entry = std::conditional_t<FIRST, NoTile, TileDesc<K_DOWN, GP ^ 1, NT - 1>>;
+            using Prev = std::conditional_t<j == 0, Entry, TileDesc<K_UP, 0, j - 1>>;
+            auto pf = [&](int s2) __attribute__((always_inline)) {
+                constexpr int j2 = j + 2;
+                if constexpr (j2 < NT) dma_up(c + 1, j2, s2); else dma_down(c, j2 - NT, s2);
+            };
+            interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+        });
+        static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
+            constexpr int d = decltype(d_tag)::value;
+            using Cur = TileDesc<K_DOWN, GP, d>;
+            using Prev = std::conditional_t<d == 0, TileDesc<K_UP, 0, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
+            auto pf = [&](int s2) __attribute__((always_inline)) {
+                constexpr int d2 = d + 2;
+                if constexpr (d2 < NT) dma_down(c, d2, s2);
+                else if (c + 2 < NC) dma_up(c + 2, d2 - NT, s2);
+                else dma_down(c + 1, d2 - NT, s2);            // chunk c+1 is the last one: only its DOWN tiles are left
+            };
+            // the 16 element pairs of gelu(c+1) behind the MFMAs of the NT intervals: pair q -> interval q / PPI, slot
+            // (q % PPI) * (16 / PPI) of its 16 MFMAs.  The first MFMAs of interval 0 finish UP(c+1): no pair before slot 8.
+            auto fill = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
+                constexpr int slot16 = decltype(grp_tag)::value * 8 + decltype(k_tag)::value;
+                constexpr int first = d == 0 ? 8 : 0;                                     // usable slots of this interval
+                constexpr int before = d == 0 ? 0 : 8 + (d - 1) * 16;                     // usable slots of earlier intervals
+                constexpr int total = 8 + (NT - 1) * 16;
+                if constexpr (slot16 >= first) {
+                    // pairs are spread evenly over the usable slots: pair q sits at usable slot floor(q * total / 16)
+                    constexpr int u = before + slot16 - first;
+                    constexpr int q = (u * 16 + total - 1) / total;                        // smallest q with q * total / 16 >= u
+                    if constexpr (q < 16 && (q * total) / 16 == u)
+                        gelu_pair(std::integral_constant<int, GP ^ 1>{}, std::integral_constant<int, q / 4>{},
+                                  std::integral_constant<int, q % 4>{}, c + 1);
+                }
+            };
+            interval(Cur{}, Prev{}, VM4{}, pf, fill);
+        });
+    };
+    step(H0{}, std::true_type{}, 0);
+    for (int c = 1; c + 1 < NC; c += 2) {
+        step(H1{}, std::false_type{}, c);
+        if (c + 2 < NC) step(H0{}, std::false_type{}, c + 1);
+    }
+    // ---- DOWN(NC-1)
+    auto last_down = [&](auto gp_tag) __attribute__((always_inline)) {
+        constexpr int GP = decltype(gp_tag)::value;
+        static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
+            constexpr int d = decltype(d_tag)::value;
+            using Cur = TileDesc<K_DOWN, GP, d>;
+            using Prev = std::conditional_t<d == 0, TileDesc<K_DOWN, GP ^ 1, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
+            auto pf = [&](int s2) __attribute__((always_inline)) {
+                constexpr int d2 = d + 2;
+                if constexpr (d2 < NT) dma_down(NC - 1, d2, s2);
+            };
+            constexpr int vm = d + 2 < NT ? 4 : 0;
+            interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing);
+        });
+        drain(TileDesc<K_DOWN, GP, NT - 1>{});
+    };
+    if ((NC - 1) & 1) last_down(H1{}); else last_down(H0{});
+
+    // ================================ LayerNorm 2 (wave-local) -> rows in S -> HBM ================================
+    {
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int hi = lane_e >> 5, lane = lane_e;
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 yv = *(const f16x8 *)(S + (2 * n + s) * 1024 + lane * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float v = acc2[n][r] + cb2[f] + (float)yv[e];
+                    acc2[n][r] = v;
+                    sum += v;
+                }
+            }
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / H);
+        float sq = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc2[n][r] - mean;
+                acc2[n][r] = d;
+                sq += d * d;
+            }
+        sq += __shfl_xor(sq, 32);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / H) + 1e-5f);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // fragment (q, lane) -> position (lane + 2q) & 63 of row q: the row-major read below is conflict-free
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int q = 2 * n + s;
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    o[e] = (_Float16)(cg2[f] * (acc2[n][r] * rstd) + cbe2[f]);
+                }
+                *(f16x8 *)(S + q * 1024 + ((lane + 2 * q) & 63) * 16) = o;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // 16-byte unit (token, 8-feature chunk c8) of the output = bytes h2*8.. of the fragments (q, token) and
+        // (q, token + 32), q = c8 >> 1, h2 = c8 & 1
+        half_t *ow = a.out + (size_t)tok_w * H;
+#pragma unroll
+        for (int st = 0; st < H / 16; ++st) {
+            const int v = st * 64 + lane, tok = v / (H / 8), c8 = v - tok * (H / 8), q = c8 >> 1, h2 = c8 & 1;
+            const char *row = S + q * 1024 + h2 * 8;
+            const f16x4 lo = *(const f16x4 *)(row + ((tok + 2 * q) & 63) * 16);
+            const f16x4 hi4 = *(const f16x4 *)(row + ((tok + 32 + 2 * q) & 63) * 16);
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi4[e]; }
+            *(f16x8 *)(ow + (size_t)tok * H + c8 * 8) = o;
+        }
+    }
+#ifdef BERT_HIP_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(tl < 119 ? 119 : 255);
+#endif
+}
+
+bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2) {
+    const int H = W1.K, I = W1.N;
+    if (Wo.type != GW_F16 || W1.type != GW_F16 || W2.type != GW_F16 || !W1.w16p || !W2.w16p) return false;
+    if (Wo.N != H || Wo.K != H || W2.N != H || W2.K != I) return false;
+    if (H % 128 != 0 || H < 256 || H > 384 || I % 64 != 0 || I < 128) return false;
+    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + I) * sizeof(float);
+    return lds <= 160 * 1024;
+}
+
+void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
+                       const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
+                       const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream) {
+    TailArgs a;
+    a.ctx = ctx; a.x = x; a.wo = Wo.w16; a.w1p = W1.w16p; a.w2p = W2.w16p;
+    a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out; a.I = W1.N;
+    const int H = W1.K, NT = H / 128;
+    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + a.I) * sizeof(float);
+    static bool configured[4] = {};
+    auto go = [&](auto kernel) __attribute__((always_inline)) {
+        if (!configured[NT]) {
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            configured[NT] = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(256), lds, stream, a);
+        TL_DUMP(M_pad >= 128 * 256, 120);
+    };
+    switch (NT) {
+        case 1: go(layer_tail_kernel<1>); break;
+        case 2: go(layer_tail_kernel<2>); break;
+        default: go(layer_tail_kernel<3>); break;
+    }
+}
+
+}  // namespace bert_hip

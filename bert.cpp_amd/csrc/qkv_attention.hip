@@ -48,10 +48,6 @@ struct QkvAttArgs {
 // 16-byte chunk swizzle of a [rows][32 halfs] tile (64-byte rows) for conflict-free ds_read_b128
 __device__ __forceinline__ int off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-__device__ __forceinline__ unsigned lds_addr(const void *p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
-}
-
 // ds_read_b128 the compiler does not track: the caller retires it with its own s_waitcnt lgkmcnt(N)
 template <int OFF>
 __device__ __forceinline__ f16x8 lds_read_b128(unsigned addr) {

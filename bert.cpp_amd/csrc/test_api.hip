@@ -209,4 +209,55 @@ int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqle
     return 0;
 }
 
+int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x, const void *Wo,
+                                 const void *W1, const void *W2, int32_t wtype, const float *bo, const float *g1,
+                                 const float *be1, const float *b1, const float *b2, const float *g2, const float *be2,
+                                 int32_t impl, uint16_t *out) {
+    std::string err;
+    HostTensor to, t1, t2;
+    to.type = wtype; to.n_dims = 2; to.ne0 = H; to.ne1 = H; to.data = (const uint8_t *)Wo; to.nbytes = wtype_row_bytes(wtype, H) * (size_t)H;
+    t1.type = wtype; t1.n_dims = 2; t1.ne0 = H; t1.ne1 = I; t1.data = (const uint8_t *)W1; t1.nbytes = wtype_row_bytes(wtype, H) * (size_t)I;
+    t2.type = wtype; t2.n_dims = 2; t2.ne0 = I; t2.ne1 = H; t2.data = (const uint8_t *)W2; t2.nbytes = wtype_row_bytes(wtype, I) * (size_t)H;
+    GemmWeightStore wo, w1, w2;
+    if (!wo.build({&to}, false, err) || !w1.build({&t1}, false, err, true) || !w2.build({&t2}, false, err, true)) {
+        fprintf(stderr, "bert_hip_test_layer_tail: %s\n", err.c_str());
+        return -1;
+    }
+    if (!wo.mfma_ok || !w1.mfma_ok || !w2.mfma_ok) return -2;
+    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    DevBuf dc, dx, dy, dout, dbo, dg1, dbe1, db1, db2, dg2, dbe2;
+    if (!dc.alloc((size_t)M_pad * H * 2, err) || !dx.alloc((size_t)M_pad * H * 2, err) || !dy.alloc((size_t)M_pad * H * 2, err) ||
+        !dout.alloc((size_t)M_pad * H * 2, err) || !dbo.upload(bo, (size_t)H * 4, err) || !dg1.upload(g1, (size_t)H * 4, err) ||
+        !dbe1.upload(be1, (size_t)H * 4, err) || !db1.upload(b1, (size_t)I * 4, err) || !db2.upload(b2, (size_t)H * 4, err) ||
+        !dg2.upload(g2, (size_t)H * 4, err) || !dbe2.upload(be2, (size_t)H * 4, err)) {
+        fprintf(stderr, "bert_hip_test_layer_tail: %s\n", err.c_str());
+        return -1;
+    }
+    CK(hipMemcpy(dc.p, ctx, (size_t)M * H * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx.p, x, (size_t)M * H * 2, hipMemcpyHostToDevice));
+    if (impl == 1) {
+        if (!layer_tail_supported(wo.w, w1.w, w2.w)) return -2;
+        launch_layer_tail(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
+                          db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
+    } else if (impl == 2) {
+        if (!proj_ffn_fused_supported(wo.w, w1.w, w2.w)) return -2;
+        launch_proj_ffn_fused(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
+                              dy.as<half_t>(), db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
+    } else {
+        // three GEMM kernels + two LayerNorm kernels
+        DevBuf dff;
+        if (!dff.alloc((size_t)M_pad * I * 2, err)) return -1;
+        launch_gemm_mfma(wo.w, dc.as<half_t>(), dbo.as<float>(), dx.as<half_t>(), dy.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
+        launch_layernorm(dy.as<half_t>(), dg1.as<float>(), dbe1.as<float>(), M_pad, H, nullptr);
+        launch_gemm_mfma(w1.w, dy.as<half_t>(), db1.as<float>(), nullptr, dff.as<half_t>(), M_pad, EPI_BIAS_GELU, nullptr);
+        launch_gemm_mfma(w2.w, dff.as<half_t>(), db2.as<float>(), dy.as<half_t>(), dout.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
+        launch_layernorm(dout.as<half_t>(), dg2.as<float>(), dbe2.as<float>(), M_pad, H, nullptr);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 }  // extern "C"

@@ -56,6 +56,23 @@ static __device__ unsigned long long g_timeline[1024 * 256];
 #define TL_DUMP(cond, nstamps) do { } while (0)
 #endif
 
+// ---- hand-issued LDS reads.  The compiler's wait insertion retires LDS reads with lgkmcnt(0) only; a wave that
+// has a matrix pipe to itself must keep reads in flight under its MFMAs, so the self-pipelined kernels issue
+// their fragment reads as asm and retire them with partial counts (LDS operations complete in order).  Rules:
+// every such read is covered by an explicit wait that names the destination registers ("+v"), and no
+// compiler-generated LDS access may sit between a group of reads and its partial wait ("memory" clobbers keep
+// them out).
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const char *)p;
+}
+template <int OFF>
+__device__ __forceinline__ f16x8 lds_read_b128_u(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+
 constexpr int FF_SLOT = 32768;                 // ring slot: 16 KiB activation k-tile + 16 KiB weight tile
 constexpr int FF_RING = 3 * FF_SLOT;
 constexpr int FF_HC = FF_RING;                 // [128][128] f16 = 32 KiB

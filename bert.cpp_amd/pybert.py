@@ -25,7 +25,7 @@ BERT_HIP_H_SYMBOLS = [
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
     "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
-    "bert_hip_version",
+    "bert_hip_test_layer_tail", "bert_hip_version",
 ]
 
 
@@ -81,6 +81,8 @@ def lib() -> C.CDLL:
     L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
     L.bert_hip_test_qkv_attention.restype = i32
     L.bert_hip_test_qkv_attention.argtypes = [i32, i32p, i32, i32, vp, vp, i32, vp, i32, vp]
+    L.bert_hip_test_layer_tail.restype = i32
+    L.bert_hip_test_layer_tail.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.bert_hip_version.restype = C.c_char_p
     _lib = L
     return L
@@ -249,6 +251,24 @@ def test_qkv_attention(x: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_hea
                                       bias.ctypes.data, 1 if fused else 0, out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_qkv_attention failed: {r}")
+    return out
+
+
+def test_layer_tail(ctx: np.ndarray, x: np.ndarray, Wo_bytes, W1_bytes, W2_bytes, wtype: int, I: int, bo, g1, be1, b1, b2,
+                    g2, be2, impl: int) -> np.ndarray:
+    """ctx, x [M][H] f16 -> layer output [M][H] f16 (out-projection + LN + FFN + LN); impl see bert_hip.h."""
+    L = lib()
+    ctx = np.ascontiguousarray(ctx, dtype=np.float16)
+    x = np.ascontiguousarray(x, dtype=np.float16)
+    M, H = ctx.shape
+    ws = [np.ascontiguousarray(w) for w in (Wo_bytes, W1_bytes, W2_bytes)]
+    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+    ps = [f(v) for v in (bo, g1, be1, b1, b2, g2, be2)]
+    out = np.zeros((M, H), dtype=np.float16)
+    r = L.bert_hip_test_layer_tail(M, H, I, ctx.ctypes.data, x.ctypes.data, ws[0].ctypes.data, ws[1].ctypes.data,
+                                   ws[2].ctypes.data, wtype, *[p.ctypes.data for p in ps], impl, out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_layer_tail failed: {r}")
     return out
 
 

@@ -62,6 +62,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
  *   BERT_HIP_ATTN          "mfma" (default) | "naive"
+ *   BERT_HIP_TAIL          1 (default) | 0 — token-owning-waves kernel for out-projection + LN + FFN + LN (f16 weights)
  *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernel for batches of long sentences
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load                            */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
@@ -98,6 +99,17 @@ BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_
 BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                              int32_t d_head, const uint16_t *x, const void *Wqkv, int32_t wtype,
                                              const float *bias, int32_t fused, uint16_t *out);
+
+/* Everything of a layer after the attention (reference bert.cpp:859-901):
+ *   y = LayerNorm(ctx Wo^T + bo + x) * g1 + be1;  out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2
+ * ctx, x, out [M][H] f16 bits; Wo [H][H], W1 [I][H], W2 [H][I] in file layout of `wtype`.
+ * impl: 0 = GEMM + LayerNorm kernels, 1 = token-owning-waves kernel (layer_tail.hip), 2 = panel kernel
+ * (ffn_fused.hip with the leading projection phase); -2 if the shape is not supported by the chosen kernel.   */
+BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x,
+                                          const void *Wo, const void *W1, const void *W2, int32_t wtype,
+                                          const float *bo, const float *g1, const float *be1, const float *b1,
+                                          const float *b2, const float *g2, const float *be2, int32_t impl,
+                                          uint16_t *out);
 
 BERT_API const char *bert_hip_version(void);
 
