@@ -1,6 +1,6 @@
 // engine.h — device side of a bert_ctx: HBM-resident weights, workspace, and the launch sequence
 // of the forward pass.  Replaces the reference's ggml arena + per-sentence graph build + execute
-// (reference bert.cpp:730-941, sizing :680-713) with a fixed 2 + 7*L kernel sequence over a packed
+// (reference bert.cpp:730-941, sizing :680-713) with a fixed kernel sequence (2 + 2*L launches on the fused path) over a packed
 // variable-length batch.
 #pragma once
 #include <hip/hip_runtime.h>

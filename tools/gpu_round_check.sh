@@ -32,6 +32,7 @@ DB=$(find $OUT/prof_stats_$TAG -name '*_results.db' | head -1)
 python tools/rocpd_summary.py stats $DB > $OUT/stats_$TAG.txt 2>&1
 for j in 1 2; do python tools/rocpd_summary.py pmc $(find $OUT/prof_pmc${j}_$TAG -name '*_results.db' | head -1) > $OUT/pmc${j}_$TAG.txt 2>&1; done
 python tools/rocpd_summary.py pmc $(find $OUT/prof_pmc3_$TAG $OUT/prof_pmc4_$TAG $OUT/prof_pmc5_$TAG -name '*_results.db') > $OUT/pmc3_$TAG.txt 2>&1
+python tools/pmc_traffic.py config1=$(find $OUT/prof_pmc3_$TAG -name '*_results.db' | head -1),$(find $OUT/prof_pmc4_$TAG -name '*_results.db' | head -1) > $OUT/traffic_$TAG.json 2>&1
 grep -h '^{' $OUT/bench_prof_$TAG.log | tail -2 > $OUT/bench_prof_line_$TAG.txt
 # raw databases are large; keep only the text summaries in gpurun_out
 rm -rf $OUT/prof_stats_$TAG $OUT/prof_pmc*_$TAG
