@@ -29,6 +29,9 @@ bool DevBuf::alloc(size_t n, std::string &err) {
     HIP_OK(hipMalloc(&p, n), err, false);
     bytes = n;
     HIP_OK(hipMemset(p, 0, n), err, false);
+    // the fill runs on the null stream and returns early; the engine's streams are non-blocking (not ordered
+    // against it), so a kernel writing this buffer could be overtaken by the fill
+    HIP_OK(hipDeviceSynchronize(), err, false);
     return true;
 }
 bool DevBuf::upload(const void *src, size_t n, std::string &err) {

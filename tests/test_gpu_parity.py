@@ -384,6 +384,25 @@ def test_encode_equals_tokenize_plus_eval(make_model, tmp_path):
         assert np.array_equal(e, m.encode(t))
 
 
+def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
+    """Growing batches make the engine reallocate (and zero-fill) its output / workspace buffers between
+    evaluations; the fill must be complete before kernels of the next pass write them (it once was not: the
+    null-stream memset overtook the pooling kernel now and then)."""
+    path, hp = make_model("tiny-h128", "q4_0", 11)
+    rng = np.random.default_rng(0)
+    sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (1, 2, 3, 4, 5, 7, 9, 12, 17, 25, 33, 48, 63, 64)]
+    m0 = pybert.BertModel(path)
+    ref = [m0.eval(s).copy() for s in sents]
+    for trial in range(12):
+        m = pybert.BertModel(path)                       # fresh context: every growth step happens again
+        for k in (1, 2, 3, 5, 8, 14):
+            idx = rng.choice(len(sents), size=k, replace=True)
+            out = m.eval_batch([sents[i] for i in idx])
+            for j, i in enumerate(idx):
+                assert np.array_equal(out[j], ref[i]), (trial, k, int(i))
+        m.close()
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes through size-independent properties
 # ------------------------------------------------------------------------------------------------
