@@ -262,11 +262,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t) {
             constexpr int e0 = 2 * p;
             const float xv = accU[fb][8 * s + e0 + t] + b[t];
-#if defined(LT_EXP) && LT_EXP == 1
-            g[par][j][e0 + t] = (_Float16)(0.5f * xv);
-#else
             g[par][j][e0 + t] = (_Float16)gelu_fast(xv);
-#endif
             accU[fb][8 * s + e0 + t] = 0.f;
         }
     };
@@ -296,7 +292,10 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int l31 = lane_e & 31, hi = lane_e >> 5, lane = lane_e;
-        float sum = 0.f;
+        // one pass over the accumulators for both moments (mean, E[v^2]); a second pass normalises with a per-feature
+        // scale and offset.  (A wave alone on its SIMD pays every VALU instruction at full price: the three-pass
+        // textbook form cost 7 us per LayerNorm.)  var = E[v^2] - mean^2 in f32: the inputs are O(1) with |mean| < std.
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
@@ -308,22 +307,15 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const float v = acc2[n][4 * gq + e] + bv[e] + (float)xv[e];
                     acc2[n][4 * gq + e] = v;
-                    sum += v;
+                    s1 += v;
+                    s2 = __builtin_fmaf(v, v, s2);
                 }
             }
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / H);
-        float sq = 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc2[n][r] - mean;
-                acc2[n][r] = d;
-                sq += d * d;
-            }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / H) + 1e-5f);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / H);
+        const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f), nmr = -mean * rstd;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every x read of the wave is done before S is rewritten
 #pragma unroll
         for (int n = 0; n < NB; ++n)
@@ -331,10 +323,16 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             for (int s = 0; s < 2; ++s) {
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    o[e] = (_Float16)(cg1[f] * (acc2[n][r] * rstd) + cbe1[f]);
-                    acc2[n][r] = 0.f;
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int f0 = 32 * n + 16 * s + 8 * hq + 4 * hi;              // registers 8s + 4hq + 0..3
+                    const f32x4 gv = *(const f32x4 *)(cg1 + f0), bv = *(const f32x4 *)(cbe1 + f0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * s + 4 * hq + e;
+                        // g * ((v - mean) * rstd) + b  =  v * (g * rstd) + (g * (-mean * rstd) + b)
+                        o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][r], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
+                        acc2[n][r] = 0.f;
+                    }
                 }
                 *(f16x8 *)(S + (2 * n + s) * 1024 + lane * 16) = o;
             }
@@ -449,37 +447,35 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     if ((NC - 1) & 1) last_down(H1{}); else last_down(H0{});
 
     // ================================ LayerNorm 2 (wave-local) -> rows in S -> HBM ================================
+    TL_STAMP(tl++);
     {
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         const int hi = lane_e >> 5, lane = lane_e;
-        float sum = 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int n = 0; n < NB; ++n)
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f16x8 yv = *(const f16x8 *)(S + (2 * n + s) * 1024 + lane * 16);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = acc2[n][r] + cb2[f] + (float)yv[e];
-                    acc2[n][r] = v;
-                    sum += v;
+                for (int hq = 0; hq < 2; ++hq) {
+                    const f32x4 bv = *(const f32x4 *)(cb2 + 32 * n + 16 * s + 8 * hq + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 8 * s + 4 * hq + e;
+                        const float v = acc2[n][r] + bv[e] + (float)yv[4 * hq + e];
+                        acc2[n][r] = v;
+                        s1 += v;
+                        s2 = __builtin_fmaf(v, v, s2);
+                    }
                 }
             }
-        sum += __shfl_xor(sum, 32);
-        const float mean = sum * (1.0f / H);
-        float sq = 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc2[n][r] - mean;
-                acc2[n][r] = d;
-                sq += d * d;
-            }
-        sq += __shfl_xor(sq, 32);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / H) + 1e-5f);
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / H);
+        const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f), nmr = -mean * rstd;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // fragment (q, lane) -> position (lane + 2q) & 63 of row q: the row-major read below is conflict-free
 #pragma unroll
@@ -489,13 +485,17 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
                 const int q = 2 * n + s;
                 f16x8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int r = 8 * s + e, f = 32 * n + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    o[e] = (_Float16)(cg2[f] * (acc2[n][r] * rstd) + cbe2[f]);
+                for (int hq = 0; hq < 2; ++hq) {
+                    const int f0 = 32 * n + 16 * s + 8 * hq + 4 * hi;
+                    const f32x4 gv = *(const f32x4 *)(cg2 + f0), bv = *(const f32x4 *)(cbe2 + f0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][8 * s + 4 * hq + e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
                 }
                 *(f16x8 *)(S + q * 1024 + ((lane + 2 * q) & 63) * 16) = o;
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        TL_STAMP(tl++);
         // 16-byte unit (token, 8-feature chunk c8) of the output = bytes h2*8.. of the fragments (q, token) and
         // (q, token + 32), q = c8 >> 1, h2 = c8 & 1
         half_t *ow = a.out + (size_t)tok_w * H;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     }
 #ifdef BERT_HIP_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TL_STAMP(tl < 119 ? 119 : 255);
+    TL_STAMP(tl++);
 #endif
 }
 
@@ -541,7 +541,7 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
             configured[NT] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(256), lds, stream, a);
-        TL_DUMP(M_pad >= 128 * 256, 120);
+        TL_DUMP(M_pad >= 128 * 256, 200);
     };
     switch (NT) {
         case 1: go(layer_tail_kernel<1>); break;
