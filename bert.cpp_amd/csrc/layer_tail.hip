@@ -235,8 +235,8 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         constexpr int VM = decltype(vm_tag)::value;
         const unsigned so = (unsigned)slot * LT_TILE;
         TL_STAMP(tl++);
-        prefetch(slot == 0 ? 2 : slot - 1);                   // slot + 2 (mod 3): read one tile ago, free since the barrier
         read_half(cur, H0{}, so);
+        prefetch(slot == 0 ? 2 : slot - 1);                   // slot + 2 (mod 3): read one tile ago, free since the barrier
         if constexpr (P::kind != K_NONE) mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) { filler(H0{}, k); });
         read_half(cur, H1{}, so);
         if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
