@@ -34,8 +34,10 @@ struct GemmWeightStore {
     DevBuf w16, w16p, qs, sc, naive16;
     bool mfma_ok = false;
     // rows: list of (file tensor) stacked along N (one entry, or q|k|v).  All share type and K.
-    // want_kperm: also build GemmWeight::w16p (f16 weights only)
-    bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm = false);
+    // want_kperm: also build GemmWeight::w16p (f16 images only); expand_q4: q4_0 / q4_1 tensors become an f16 image at
+    // load (default for the engine) instead of the nibble / scale planes of the fused-dequant kernels
+    bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm = false,
+               bool expand_q4 = false);
 };
 
 struct LayerWeights {
@@ -84,7 +86,7 @@ private:
     hipStream_t stream_ = nullptr;
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, tail_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, tail_ = true, q4_expand_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

@@ -75,8 +75,8 @@ void row_to_f16(const HostTensor &t, int64_t r, _Float16 *dst) {
                     dst[b * 32 + j] = (_Float16)((float)(q0 - 8) * d);
                     dst[b * 32 + j + 16] = (_Float16)((float)(q1 - 8) * d);
                 } else {
-                    dst[b * 32 + j] = (_Float16)((float)q0 * d + m);
-                    dst[b * 32 + j + 16] = (_Float16)((float)q1 * d + m);
+                    dst[b * 32 + j] = (_Float16)((double)q0 * d + m);          // exact in double: one rounding, like an f16 fma
+                    dst[b * 32 + j + 16] = (_Float16)((double)q1 * d + m);
                 }
             }
         }
@@ -85,7 +85,8 @@ void row_to_f16(const HostTensor &t, int64_t r, _Float16 *dst) {
 
 }  // namespace
 
-bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm) {
+bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm,
+                            bool expand_q4) {
     const int64_t K = rows[0]->ne0;
     const int ftype = rows[0]->type;
     int64_t N = 0;
@@ -100,7 +101,9 @@ bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool wa
         for (auto *c : rows) { if (n < c->ne1) { t = c; r = n; return; } n -= c->ne1; }
         t = nullptr; r = 0;
     };
-    const bool quant = ftype == W_Q4_0 || ftype == W_Q4_1;
+    // expand_q4: the 4-bit blocks become an f16 image here, once (same values the fused-dequant kernels build in
+    // registers on every tile); the matrix then runs on the f16 kernels
+    const bool quant = (ftype == W_Q4_0 || ftype == W_Q4_1) && !expand_q4;
     if (mfma_ok && !quant) {
         w.type = GW_F16;
         std::vector<_Float16> img((size_t)w.N_pad * K, (_Float16)0);
@@ -189,6 +192,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -206,16 +210,16 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
         auto *L = new LayerWeights;
         e->layers_.push_back(L);
         ok = ok && L->qkv.build({T(p + "attention.self.query.weight"), T(p + "attention.self.key.weight"),
-                                 T(p + "attention.self.value.weight")}, want_naive, err);
+                                 T(p + "attention.self.value.weight")}, want_naive, err, false, e->q4_expand_);
         ok = ok && concat_upload(L->qkv_b, {T(p + "attention.self.query.bias"), T(p + "attention.self.key.bias"),
                                             T(p + "attention.self.value.bias")}, err);
-        ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err);
+        ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err, false, e->q4_expand_);
         ok = ok && upload_f32(L->o_b, T(p + "attention.output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_att_w, T(p + "attention.output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_att_b, T(p + "attention.output.LayerNorm.bias"), err);
-        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, true);
+        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, true, e->q4_expand_);
         ok = ok && upload_f32(L->ffi_b, T(p + "intermediate.dense.bias"), err);
-        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, true);
+        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, true, e->q4_expand_);
         ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);

@@ -41,7 +41,6 @@ struct FfnArgs {
     const float *bo, *g1, *beta1;
     half_t *ybuf;            // [T_pad][H]
     int I;
-    int skip;              // tuning aid (BERT_HIP_FFN_SKIP): 1 = no final epilogue, 2 = no main loop
 };
 
 template <int NT, int WT, bool PROJ>
@@ -302,13 +301,8 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
         sbase += TPC % 3;
         sbase = sbase >= 3 ? sbase - 3 : sbase;
     };
-    if (!(a.skip & 2)) {
-        for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
-        chunk(std::true_type{}, NC - 1);
-    } else {
-        wait_vm_barrier<0>();
-    }
-    if (a.skip & 1) { if (acc2[0][0][0] == 12345.f) a.out[0] = (_Float16)1; return; }
+    for (int c = 0; c < NC - 1; ++c) chunk(std::false_type{}, c);
+    chunk(std::true_type{}, NC - 1);
 
     // ---- final epilogue: + b2 + residual (the block input y), LayerNorm, gamma/beta, full-row stores
     // (opaque copies of the lane ids: keeps the compiler from carrying the PROJ phase's epilogue addresses
@@ -330,9 +324,6 @@ bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2) {
 
 static void launch_ffn_impl(FfnArgs &a, const GemmWeight &W1, bool proj, int M_pad, hipStream_t stream) {
     a.I = W1.N;
-    static int skip = -1;
-    if (skip < 0) { const char *e = getenv("BERT_HIP_FFN_SKIP"); skip = e ? atoi(e) : 0; }
-    a.skip = skip;
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512 + (proj ? 3 * H : 0)) * sizeof(float);
     const int grid = M_pad / 128;

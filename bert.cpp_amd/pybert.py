@@ -25,7 +25,7 @@ BERT_HIP_H_SYMBOLS = [
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
     "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
-    "bert_hip_test_layer_tail", "bert_hip_version",
+    "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_version",
 ]
 
 

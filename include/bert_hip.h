@@ -62,6 +62,8 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
  *   BERT_HIP_ATTN          "mfma" (default) | "naive"
+ *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
+ *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
  *   BERT_HIP_TAIL          1 (default) | 0 — token-owning-waves kernel for out-projection + LN + FFN + LN (f16 weights)
  *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernel for batches of long sentences
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load                            */
@@ -110,6 +112,10 @@ BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const
                                           const float *bo, const float *g1, const float *be1, const float *b1,
                                           const float *b2, const float *g2, const float *be2, int32_t impl,
                                           uint16_t *out);
+
+/* Average milliseconds of `iters` launches of the fused feed-forward kernel on device-resident random data
+ * (tuning helper of tools/bench_ffn.py; negative on error).                                              */
+BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters);
 
 BERT_API const char *bert_hip_version(void);
 

@@ -384,6 +384,26 @@ def test_encode_equals_tokenize_plus_eval(make_model, tmp_path):
         assert np.array_equal(e, m.encode(t))
 
 
+@pytest.mark.parametrize("dims,ftype", [("tiny-h128", "q4_0"), ("tiny-d64", "q4_1"), ("minilm-l6", "q4_0"), ("tiny", "q4_1")])
+def test_q4_expanded_at_load_equals_fused_dequant(make_model, dims, ftype, monkeypatch):
+    """q4 weight matrices are expanded to f16 images once at load by default (BERT_HIP_Q4=expand) and then run the
+    f16 kernels; BERT_HIP_Q4=fused keeps the 4-bit planes and dequantises inside the GEMM kernels.  Same weight
+    values either way: the embeddings agree to f16-accumulation-order noise and both match the oracle."""
+    path, hp = make_model(dims, ftype, 5)
+    rng = np.random.default_rng(3)
+    lens = [5, 64, 17, 33, 64] if hp.n_max_tokens < 128 else [128, 90, 7, 128, 64]
+    sents = [rng.integers(0, hp.n_vocab, size=min(n, hp.n_max_tokens)).astype(np.int32) for n in lens]
+    a = pybert.BertModel(path).eval_batch(sents)
+    monkeypatch.setenv("BERT_HIP_Q4", "fused")
+    b = pybert.BertModel(path).eval_batch(sents)
+    monkeypatch.delenv("BERT_HIP_Q4")
+    ref = orc.Oracle(path)
+    for i, s in enumerate(sents):
+        assert cosine(a[i], b[i]) > 1 - 2e-5, (i, cosine(a[i], b[i]))
+        want = ref.eval(s)
+        assert cosine(a[i], want) > 0.99 and cosine(b[i], want) > 0.99
+
+
 def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
     """Growing batches make the engine reallocate (and zero-fill) its output / workspace buffers between
     evaluations; the fill must be complete before kernels of the next pass write them (it once was not: the
