@@ -106,8 +106,9 @@ def committed_traffic(cfg_id, kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return t.get(f"config{cfg_id}", {}).get(kernel)
-    except (OSError, ValueError):
+        d = t.get(f"config{cfg_id}", {}).get(kernel)
+        return None if d is None else d["bytes"]
+    except (OSError, ValueError, KeyError):
         return None
 
 
