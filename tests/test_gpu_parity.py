@@ -404,6 +404,26 @@ def test_q4_expanded_at_load_equals_fused_dequant(make_model, dims, ftype, monke
         assert cosine(a[i], want) > 0.99 and cosine(b[i], want) > 0.99
 
 
+@pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL", "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
+def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
+    """The fused kernels each have a fallback family (token-owning layer tail -> 128-token panel kernels -> tiled GEMMs
+    + LayerNorm kernels; fused projection+attention -> QKV GEMM + attention kernel).  On the benchmark's dimensions
+    every family must give the same embeddings up to accumulation-order noise, and match the oracle."""
+    path, hp = make_model("minilm-l6", "f16", 2)
+    rng = np.random.default_rng(4)
+    sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (128, 128, 96, 128, 77, 128)]
+    base = pybert.BertModel(path).eval_batch(sents)
+    for k in knob.split("+"):
+        monkeypatch.setenv(k, "0")
+    alt = pybert.BertModel(path).eval_batch(sents)
+    for k in knob.split("+"):
+        monkeypatch.delenv(k)
+    want = orc.Oracle(path).eval(sents[2])
+    assert cosine(base[2], want) > 1 - 1e-4 and cosine(alt[2], want) > 1 - 1e-4
+    for i in range(len(sents)):
+        assert cosine(base[i], alt[i]) > 1 - 1e-6, (knob, i, cosine(base[i], alt[i]))
+
+
 def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
     """Growing batches make the engine reallocate (and zero-fill) its output / workspace buffers between
     evaluations; the fill must be complete before kernels of the next pass write them (it once was not: the
