@@ -324,7 +324,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
 
     timed("embed_ln", 0.0, s, [&] {
         launch_embed_ln(word_emb_.p, type_emb_.p, pos_emb_.p, table_type_, ln_e_w_.as<float>(), ln_e_b_.as<float>(),
-                        d_tokens, d_cu, B, T, H, hp_.n_vocab, x, s);
+                        d_tokens, d_cu, B, T, H, hp_.n_vocab, max_len, x, s);
     });
     tap(0);
     // attention FLOPs: 4 * sum_b N_b^2 * H; only T and max_len are known here -> upper bound T * max_len

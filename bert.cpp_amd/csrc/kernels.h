@@ -66,7 +66,7 @@ void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, 
 // word + token_type(0) + position gather-sum, LayerNorm(eps 1e-5), f16 out.  Tables in file layout.
 void launch_embed_ln(const void *word, const void *type, const void *pos, int table_type, const float *gamma,
                      const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
-                     int H, int n_vocab, half_t *out, hipStream_t stream);
+                     int H, int n_vocab, int max_len, half_t *out, hipStream_t stream);
 
 // In-place LayerNorm over H of f16 rows (eps 1e-5), gamma/beta f32.
 void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, int H, hipStream_t stream);

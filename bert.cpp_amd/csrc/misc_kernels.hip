@@ -104,10 +104,88 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const v
     }
 }
 
+// Same operation for f32 / f16 tables with H % 8 == 0, laid out for bandwidth: the grid is (4-token group, sentence), so
+// a wave knows its sentence and position without searching cu_seqlens; a lane owns 16-byte runs of the row (8
+// features: one 16-byte load per f16 table row, one 16-byte store), NC runs per lane (H <= 512 * NC).
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+template <int TT>
+__device__ __forceinline__ void table_run8(const void *tab, int H, int r, int e0, float (&v)[8]) {
+    if (TT == 0) {
+        const float4 a = *(const float4 *)((const float *)tab + (size_t)r * H + e0);
+        const float4 b = *(const float4 *)((const float *)tab + (size_t)r * H + e0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const f16x8m h = *(const f16x8m *)((const half_t *)tab + (size_t)r * H + e0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    }
+}
+template <int TT, int NC>
+__global__ __launch_bounds__(256) void embed_ln_rows_kernel(const void *word, const void *type, const void *pos,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            const int32_t *__restrict__ tokens,
+                                                            const int32_t *__restrict__ cu_seqlens, int H, int n_vocab,
+                                                            half_t *__restrict__ out) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // position in the sentence
+    const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
+    if (p >= n) return;
+    const int t = tok0 + p;
+    int id = tokens[t];
+    id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);   // ids are validated on the host API; clamp for safety
+    float v[NC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int e0 = 8 * (lane + 64 * j);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][i] = 0.f;
+        if (e0 < H) {
+            float w[8], ty[8], ps[8];
+            table_run8<TT>(word, H, id, e0, w);
+            table_run8<TT>(type, H, 0, e0, ty);
+            table_run8<TT>(pos, H, p, e0, ps);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[j][i] = ps[i] + (ty[i] + w[i]); sum += v[j][i]; }
+        }
+    }
+    const float mean = wave_sum(sum) / H;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+        if (8 * (lane + 64 * j) < H)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { v[j][i] -= mean; sq += v[j][i] * v[j][i]; }
+    const float rstd = 1.0f / sqrtf(wave_sum(sq) / H + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const int e0 = 8 * (lane + 64 * j);
+        if (e0 < H) {
+            const float4 g0 = *(const float4 *)(gamma + e0), g1 = *(const float4 *)(gamma + e0 + 4);
+            const float4 b0 = *(const float4 *)(beta + e0), b1 = *(const float4 *)(beta + e0 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            f16x8m o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (_Float16)(gg[i] * (v[j][i] * rstd) + bb[i]);
+            *(f16x8m *)(out + (size_t)t * H + e0) = o;
+        }
+    }
+}
+
 void launch_embed_ln(const void *word, const void *type, const void *pos, int table_type, const float *gamma,
                      const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
-                     int H, int n_vocab, half_t *out, hipStream_t stream) {
+                     int H, int n_vocab, int max_len, half_t *out, hipStream_t stream) {
     if (T <= 0) return;
+    if (table_type <= 1 && H % 8 == 0 && H <= 1024 && max_len > 0 && n_sentences <= 65535) {
+        const dim3 g2((max_len + 3) / 4, n_sentences), b2(256);
+#define EMBR(TT, NC) hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
+                                        cu_seqlens, H, n_vocab, out)
+        if (table_type == 0) { if (H <= 512) EMBR(0, 1); else EMBR(0, 2); }
+        else { if (H <= 512) EMBR(1, 1); else EMBR(1, 2); }
+#undef EMBR
+        return;
+    }
     const dim3 grid((T + 3) / 4), block(256);
     const int nj = (H + 127) / 128;
 #define EMB(NJ) hipLaunchKernelGGL(embed_ln_kernel<NJ>, grid, block, 0, stream, word, type, pos, table_type, gamma, \
