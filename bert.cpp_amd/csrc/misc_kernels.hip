@@ -255,14 +255,29 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, co
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
     const float invn = 1.0f / (float)n;
-    for (int e = 2 * lane; e < H; e += 128) {
-        float a0 = 0.f, a1 = 0.f;
+    if (H % 8 == 0) {
+        // 16-byte runs per lane (same per-element summation order as the pair loop below)
+        for (int c = lane; c < H / 8; c += 64) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int t = wave; t < n; t += 4) {
-            const f16x2 v = *(const f16x2 *)(x + (size_t)(tok0 + t) * H + e);
-            a0 += (float)v[0] * invn; a1 += (float)v[1] * invn;
+            for (int t = wave; t < n; t += 4) {
+                const f16x8m v = *(const f16x8m *)(x + (size_t)(tok0 + t) * H + 8 * c);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += (float)v[i] * invn;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[wave * H + 8 * c + i] = acc[i];
         }
-        part[wave * H + e] = a0; part[wave * H + e + 1] = a1;
+    } else {
+        for (int e = 2 * lane; e < H; e += 128) {
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll 8
+            for (int t = wave; t < n; t += 4) {
+                const f16x2 v = *(const f16x2 *)(x + (size_t)(tok0 + t) * H + e);
+                a0 += (float)v[0] * invn; a1 += (float)v[1] * invn;
+            }
+            part[wave * H + e] = a0; part[wave * H + e + 1] = a1;
+        }
     }
     __syncthreads();
     float sq = 0.f;
