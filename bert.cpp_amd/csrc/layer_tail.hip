@@ -11,20 +11,20 @@
 //     of 16 k (GemmWeight::w16p), so no shuffle is needed;
 //   * both LayerNorms are wave-local (row statistics = the lane's registers + one cross-half shuffle), y is
 //     never written to HBM, and there is no barrier between a GEMM and its epilogue;
-//   * the GELU of chunk c runs as VALU filler under the MFMAs of the NEXT chunk's up-projection (two sets of
-//     up-projection accumulators), so the matrix pipe does not wait for it.
+//   * the GELU of chunk c+1 is issued as VALU filler between the MFMAs of chunk c's down-projection (one set of up-
+//     projection accumulators, two GELU'ed chunks in flight), so the matrix pipe waits for the first chunk's GELU only.
 // The intermediate dimension is processed in chunks of 64 features (up-projection tile = [64 rows x 128 k], down-
-// projection tile = [128 rows x 64 k]): small enough for two sets of up-projection accumulators next to the 192
-// output accumulators without a single spill — a scratch reload inside the tile loop would queue behind the
-// weight tiles in flight (vmcnt is in-order) and serialise the whole pipeline.
+// projection tile = [128 rows x 64 k]): 32 up-projection accumulator registers next to the 192 output accumulators fit
+// the 256 AccVGPRs, and the tile loop runs without a single spill — a scratch reload inside the loop would queue behind
+// the weight tiles in flight (vmcnt is in-order) and serialise the whole pipeline.
 // Only the weight tiles (16 KiB) are shared: they stream through a 3-slot LDS ring by LDS-DMA,
 // two tiles ahead, one barrier per tile.  Each wave hides its own LDS latency (tile_stream.h, hand-issued reads):
 // the fragments of a tile are read in two halves, and the second half's MFMAs run after the next barrier, under
 // the reads of the next tile.
 //
 // LDS: 4 x 24 KiB wave-private staging (x rows -> y fragments -> output rows), 48 KiB ring, biases / LayerNorm
-// parameters.  Registers (H = 384): 192 output accumulators + 2 x 32 up-projection accumulators + 16 (GELU'ed
-// chunk) + 64 weight fragments + 32 y fragments.
+// parameters.  Registers (H = 384): 192 output accumulators + 32 up-projection accumulators + 2 x 16 (GELU'ed
+// chunks) + 64 weight fragments + 32 y fragments.
 #include "tile_stream.h"
 
 namespace bert_hip {
