@@ -205,6 +205,8 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     ok = ok && upload_f32(e->ln_e_w_, T("embeddings.LayerNorm.weight"), err);
     ok = ok && upload_f32(e->ln_e_b_, T("embeddings.LayerNorm.bias"), err);
     const bool want_naive = e->gemm_naive_;
+    // the k-permuted second image of the FFN weights is only read by layer_tail_kernel (H = 256 / 384)
+    const bool want_kperm = mf.hp.n_embd % 128 == 0 && mf.hp.n_embd >= 256 && mf.hp.n_embd <= 384;
     for (int i = 0; ok && i < mf.hp.n_layer; ++i) {
         const std::string p = "encoder.layer." + std::to_string(i) + ".";
         auto *L = new LayerWeights;
@@ -217,9 +219,9 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
         ok = ok && upload_f32(L->o_b, T(p + "attention.output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_att_w, T(p + "attention.output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_att_b, T(p + "attention.output.LayerNorm.bias"), err);
-        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, true, e->q4_expand_);
+        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_);
         ok = ok && upload_f32(L->ffi_b, T(p + "intermediate.dense.bias"), err);
-        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, true, e->q4_expand_);
+        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_);
         ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
