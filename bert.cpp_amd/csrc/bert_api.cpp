@@ -8,11 +8,13 @@
 //   bert_encode_batch    bert.cpp:952-1022   accessors          bert.cpp:111-134
 //   bert_params_parse    bert.cpp:140-193
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bert.h"
@@ -160,22 +162,52 @@ void bert_eval(struct bert_ctx *ctx, int32_t n_threads, bert_vocab_id *tokens, i
     bert_eval_batch(ctx, n_threads, 1, &tokens, &n_tokens, embeddings ? &embeddings : nullptr);
 }
 
+// Tokenizes n_inputs texts into tokens[i * n_max_tokens ..] on up to n_threads host threads (the tokenizer is
+// const and re-entrant; inputs are handed out in blocks of 16 from a shared counter).
+static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
+                          bert_vocab_id *tokens, int32_t *n_tokens) {
+    const int32_t N = ctx->hp.n_max_tokens;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    int nt = std::min<int>({n_threads > 0 ? n_threads : 1, (int)hw, (n_inputs + 31) / 32});
+    if (nt <= 1) {
+        for (int32_t i = 0; i < n_inputs; ++i) ctx->tok.tokenize(texts[i], tokens + (size_t)i * N, &n_tokens[i], N);
+        return;
+    }
+    std::atomic<int32_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const int32_t i0 = next.fetch_add(16);
+            if (i0 >= n_inputs) break;
+            const int32_t i1 = std::min(n_inputs, i0 + 16);
+            for (int32_t i = i0; i < i1; ++i) ctx->tok.tokenize(texts[i], tokens + (size_t)i * N, &n_tokens[i], N);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+}
+
 void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batch_size*/, int32_t n_inputs,
                        const char **texts, float **embeddings) {
     if (n_inputs <= 0) return;
     const int32_t N = ctx->hp.n_max_tokens;
-    // tokenize everything, then evaluate as packed device batches (the reference sorts by length and
-    // loops with batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching)
+    // tokenize everything (on n_threads host threads: at 10^5 sentences/s on the GPU the tokenizer is the stage in
+    // front of the path that has to keep up), then evaluate as packed device batches (the reference sorts by length
+    // and loops with batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching)
     std::vector<bert_vocab_id> buf((size_t)N * n_inputs);
     std::vector<int32_t> n_tokens(n_inputs);
     std::vector<bert_vocab_id *> ptrs(n_inputs);
-    bert_vocab_id *it = buf.data();
-    for (int32_t i = 0; i < n_inputs; ++i) {
-        ptrs[i] = it;
-        ctx->tok.tokenize(texts[i], it, &n_tokens[i], N);
-        it += n_tokens[i];
-    }
+    for (int32_t i = 0; i < n_inputs; ++i) ptrs[i] = buf.data() + (size_t)i * N;
+    tokenize_many(ctx, n_threads, n_inputs, texts, buf.data(), n_tokens.data());
     bert_eval_batch(ctx, n_threads, n_inputs, ptrs.data(), n_tokens.data(), embeddings);
+}
+
+int32_t bert_hip_tokenize_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
+                                bert_vocab_id *tokens, int32_t *n_tokens) {
+    if (!ctx || n_inputs < 0 || (n_inputs > 0 && (!texts || !tokens || !n_tokens))) return -1;
+    tokenize_many(ctx, n_threads, n_inputs, texts, tokens, n_tokens);
+    return 0;
 }
 
 void bert_encode(struct bert_ctx *ctx, int32_t n_threads, const char *texts, float *embeddings) {

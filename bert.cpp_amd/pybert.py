@@ -21,7 +21,7 @@ BERT_H_SYMBOLS = [
     "bert_eval", "bert_eval_batch", "bert_n_embd", "bert_n_max_tokens", "bert_vocab_id_to_token",
 ]
 BERT_HIP_H_SYMBOLS = [
-    "bert_hip_load_tokenizer", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
+    "bert_hip_load_tokenizer", "bert_hip_tokenize_batch", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
     "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
     "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
     "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
@@ -83,6 +83,8 @@ def lib() -> C.CDLL:
     L.bert_hip_test_qkv_attention.argtypes = [i32, i32p, i32, i32, vp, vp, i32, vp, i32, vp]
     L.bert_hip_test_layer_tail.restype = i32
     L.bert_hip_test_layer_tail.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.bert_hip_tokenize_batch.restype = i32
+    L.bert_hip_tokenize_batch.argtypes = [vp, i32, i32, C.POINTER(C.c_char_p), i32p, i32p]
     L.bert_hip_version.restype = C.c_char_p
     _lib = L
     return L
@@ -129,6 +131,15 @@ class BertModel:
         data = text if isinstance(text, bytes) else text.encode("utf-8")
         self.lib.bert_tokenize(self.ctx, data, buf, C.byref(n), n_max)
         return list(buf[: n.value])
+
+    def tokenize_batch(self, texts: Sequence[str | bytes], n_threads: int = 6) -> List[List[int]]:
+        n, N = len(texts), self.n_max_tokens
+        arr = (C.c_char_p * n)(*[t if isinstance(t, bytes) else t.encode("utf-8") for t in texts])
+        toks = np.zeros((n, N), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        if self.lib.bert_hip_tokenize_batch(self.ctx, n_threads, n, arr, _i32p(toks), _i32p(cnt)) != 0:
+            raise RuntimeError("bert_hip_tokenize_batch failed")
+        return [toks[i, : cnt[i]].tolist() for i in range(n)]
 
     def id_to_token(self, i: int) -> bytes:
         return self.lib.bert_vocab_id_to_token(self.ctx, i)

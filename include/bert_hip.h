@@ -18,6 +18,12 @@ extern "C" {
  * (Tokenization is CPU-only in the reference as well: bert.cpp:199-325.)                        */
 BERT_API struct bert_ctx *bert_hip_load_tokenizer(const char *fname);
 
+/* bert_tokenize for many texts on up to n_threads host threads (what bert_encode_batch does before it evaluates):
+ * tokens[i * bert_n_max_tokens(ctx) ..] receives the ids of texts[i], n_tokens[i] their count.  Works on
+ * tokenizer-only contexts.  Returns 0, negative on bad arguments.                                             */
+BERT_API int32_t bert_hip_tokenize_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
+                                         bert_vocab_id *tokens, int32_t *n_tokens);
+
 /* Model facts from the file header (reference bert.cpp:361-367).                                */
 BERT_API int32_t bert_hip_n_layer(struct bert_ctx *ctx);
 BERT_API int32_t bert_hip_n_head(struct bert_ctx *ctx);

@@ -127,6 +127,20 @@ def test_tokenizer_fuzz_matches_oracle(fuzz_vocab_model):
         assert m.id_to_token(i) == o.id_to_token(i)
 
 
+def test_tokenize_batch_on_threads_equals_one_by_one(fuzz_vocab_model):
+    """bert_hip_tokenize_batch (the first stage of bert_encode_batch) on 1, 4 and 9 threads gives, text for text, the
+    ids of bert_tokenize."""
+    m = libbert.BertModel(fuzz_vocab_model, tokenizer_only=True)
+    rnd = random.Random(77)
+    texts = [random_text(rnd) for _ in range(1000)]
+    with silenced_stderr():
+        want = [m.tokenize(t) for t in texts]
+        for n_threads in (1, 4, 9):
+            assert m.tokenize_batch(texts, n_threads) == want
+        assert m.tokenize_batch([], 4) == []
+        assert m.tokenize_batch(texts[:3], 64) == want[:3]
+
+
 def test_tokenizer_on_reference_corpus_if_present(sparse_vocab_model):
     """Real text (reference examples/sample_client_texts.txt) when the reference tree is mounted."""
     path = "/root/reference/examples/sample_client_texts.txt"
