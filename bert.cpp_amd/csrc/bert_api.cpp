@@ -57,6 +57,7 @@ bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
     std::unique_ptr<bert_ctx> ctx(new bert_ctx);
     ctx->hp = mf.hp;
     ctx->tok.build(std::move(mf.vocab));
+    ctx->tok.quiet = quiet;           // BERT_HIP_QUIET also drops the reference's per-byte "unknown token" stderr lines
     if (!tokenizer_only) {
         Engine *e = Engine::create(mf, err);
         if (!e) {

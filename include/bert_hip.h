@@ -72,7 +72,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
  *   BERT_HIP_TAIL          1 (default) | 0 — token-owning-waves kernel for out-projection + LN + FFN + LN (f16 weights)
  *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernel for batches of long sentences
- *   BERT_HIP_QUIET         1 = no progress text on stdout during load                            */
+ *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize                            */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 /* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
