@@ -38,7 +38,9 @@ constexpr int QA_VT_LD = QA_TOK + 4;             // halfs per V^T row (8-byte sk
 
 struct QkvAttArgs {
     const half_t *x;         // [T_pad][H] hidden state (rows of a sentence are contiguous)
-    const half_t *w;         // [3H (padded)][H] f16: Q rows, K rows, V rows
+    const half_t *w;         // [3H (padded)][H] f16: Q rows, K rows, V rows                       (WT == GW_F16)
+    const uint4 *qs;         // q4 nibble plane, tile-contiguous (kernels.h GemmWeight)             (WT != GW_F16)
+    const void *sc;          // q4 scale plane
     const float *bias;       // [3H]
     const int32_t *cu;       // [n_sentences + 1]
     half_t *out;             // [T_pad][H] attention context
@@ -71,13 +73,29 @@ __device__ __forceinline__ void gload_untracked(f32x4 &v, const float *p) {
 __device__ __forceinline__ void gload_untracked(float &v, const float *p) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p));
 }
+// q4 block of this lane (16 B of nibbles + scale) as untracked loads, and the counted wait that hands a fetched tile
+// (and, on a head's last tile, the bias registers) to its consumers
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Q4Pend { u32x4 q; unsigned sc; };             // native vector types: asm operands
+template <int WT>
+__device__ __forceinline__ void q4_fetch_untracked(Q4Pend &r, const uint4 *qs, const void *sc, size_t bi) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.q) : "v"(qs + bi));
+    if (WT == GW_Q4_0) asm volatile("global_load_ushort %0, %1, off" : "=v"(r.sc) : "v"((const unsigned short *)sc + bi));
+    else asm volatile("global_load_dword %0, %1, off" : "=v"(r.sc) : "v"((const unsigned *)sc + bi));
+}
+__device__ __forceinline__ void wait_vm2_q4(Q4Pend &r) {
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(r.q), "+v"(r.sc) : : "memory");
+}
+__device__ __forceinline__ void wait_vm2_q4_bias(Q4Pend &r, f32x4 &b0, f32x4 &b1, f32x4 &b2, f32x4 &b3, float &bv) {
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(r.q), "+v"(r.sc), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(bv) : : "memory");
+}
 __device__ __forceinline__ void wait_vm4_bias(f32x4 &b0, f32x4 &b1, f32x4 &b2, f32x4 &b3, float &bv) {
     asm volatile("s_waitcnt vmcnt(4)" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(bv) : : "memory");
 }
 
 }  // namespace
 
-template <int KT>                                // H = 64 * KT = 32 * n_head
+template <int KT, int WT>                        // H = 64 * KT = 32 * n_head; WT = weight type (q4: KT even)
 __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 64 * KT;
@@ -121,17 +139,45 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
             loffW[i] = (unsigned)(r * H + ch * 8) * 2u;
         }
         const int ntiles = n_head * KT;
-        auto issue = [&](int t, int slot) {                   // tile t = head (t / KT), k-tile (t % KT)
+        // f16: tile t goes straight into ring slot `slot` by LDS-DMA.  q4_0 / q4_1: the lane fetches its block of the
+        // tile (row lane >> 1, k-block lane & 1; the 64 blocks of a wave's tile are contiguous in the weight planes) into
+        // pend[t & 1] and expands it into the slot one tile later (expand), dequantised exactly like the panel kernels.
+        Q4Pend pend[2] = {{{0, 0, 0, 0}, 0}, {{0, 0, 0, 0}, 0}};
+        auto issue = [&](auto par_tag, int t, int slot) __attribute__((always_inline)) {    // tile t = head (t / KT), k-tile (t % KT)
             t = t < ntiles ? t : ntiles - 1;                  // past the end: re-read the last tile into a dead slot
             const int h = t / KT, kt = t - h * KT;
-            const half_t *src = wg + (size_t)h * 32 * H + kt * 64;
+            if (WT == GW_F16) {
+                const half_t *src = wg + (size_t)h * 32 * H + kt * 64;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)src + loffW[i]), AS_LDS(ring + slot * QA_WSLOT + i * 1024), 16, 0, 0);
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)src + loffW[i]), AS_LDS(ring + slot * QA_WSLOT + i * 1024), 16, 0, 0);
+            } else {
+                const int nrow = g * H + h * 32;              // first of the 32 rows, inside one 128-row tile of the planes
+                const size_t bi = ((size_t)((nrow >> 7) * KT + kt) * 128 + (nrow & 127)) * 2 + lane;
+                q4_fetch_untracked<WT>(pend[decltype(par_tag)::value], a.qs, a.sc, bi);
+            }
         };
-        issue(0, 0);
-        issue(1, 1);
+        auto expand = [&](auto par_tag, int slot) __attribute__((always_inline)) {
+            if (WT != GW_F16) {
+                const Q4Pend &pr = pend[decltype(par_tag)::value];
+                QRegs r;
+                r.q.x = pr.q[0]; r.q.y = pr.q[1]; r.q.z = pr.q[2]; r.q.w = pr.q[3]; r.sc = pr.sc;
+                char *tile = ring + slot * QA_WSLOT;
+                const int row = lane >> 1, blk = lane & 1;
+                q4_expand_to_lds<WT>(r, tile, (row << 2) | (blk << 1) | 0);      // elements 0-15 of the block
+                q4_expand_to_lds<WT>(r, tile, (row << 2) | (blk << 1) | 1);      // elements 16-31
+                asm volatile("" ::: "memory");               // the stores stay above the hand-issued reads of the slot
+            }
+        };
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        issue(P0{}, 0, 0);
+        issue(P1{}, 1, 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // B0: x panel complete
+        if (WT != GW_F16) {
+            asm volatile("" : "+v"(pend[0].q), "+v"(pend[0].sc), "+v"(pend[1].q), "+v"(pend[1].sc));   // landed (vmcnt(0) above)
+            expand(P0{}, 0);
+        }
 
         // per-lane LDS byte addresses of the fragments (ds_read_b128 issued by hand below)
         unsigned aWl[4], aXl[4], aXh[4];
@@ -220,14 +266,22 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
                             gload_untracked(bvv, bias_g + h * 32 + l31);
                         }
                     }
-                    issue(t + 2, slot == 0 ? 2 : slot - 1);
+                    using PT = std::integral_constant<int, kt & 1>;          // parity of t (q4: KT is even)
+                    using PN = std::integral_constant<int, (kt + 1) & 1>;
+                    issue(PT{}, t + 2, slot == 0 ? 2 : slot - 1);
                     wait_half(H0{});
                     mma_half(H0{});
                     if (h < 3) TL_STAMP_AT(tl_sel, tl++);
-                    // tile t+1 has landed once at most the 4 pieces of tile t+2 are outstanding (so have the older
-                    // bias loads: the last tile's wait hands them to the epilogue)
-                    if (kt == KT - 1) wait_vm4_bias(bqk[0], bqk[1], bqk[2], bqk[3], bvv);
-                    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    // tile t+1 has landed once at most the pieces of tile t+2 are outstanding (so have the older bias
+                    // loads: the last tile's wait hands them to the epilogue)
+                    if (WT == GW_F16) {
+                        if (kt == KT - 1) wait_vm4_bias(bqk[0], bqk[1], bqk[2], bqk[3], bvv);
+                        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    } else {
+                        if (kt == KT - 1) wait_vm2_q4_bias(pend[PN::value], bqk[0], bqk[1], bqk[2], bqk[3], bvv);
+                        else wait_vm2_q4(pend[PN::value]);
+                        expand(PN{}, slot == 2 ? 0 : slot + 1);              // tile t+1 -> its slot (read one tile ago)
+                    }
                     read_half(std::integral_constant<int, (kt + 1) % KT>{}, H0{}, so1);
                     wait_half(H1{});
                     mma_half(H1{});
@@ -370,32 +424,46 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
 
 bool qkv_attention_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len) {
     const int H = n_head * d_head;
-    return Wqkv.type == GW_F16 && d_head == 32 && Wqkv.K == H && Wqkv.N == 3 * H && H % 64 == 0 && H <= 384 &&
-           max_len <= QA_TOK;
+    if (!(d_head == 32 && Wqkv.K == H && Wqkv.N == 3 * H && H % 64 == 0 && H <= 384 && max_len <= QA_TOK)) return false;
+    return Wqkv.type == GW_F16 || H % 128 == 0;              // q4: an even number of k-tiles per head
 }
 
 void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
                           int n_sentences, int n_head, half_t *out, hipStream_t stream) {
     QkvAttArgs a;
-    a.x = x; a.w = Wqkv.w16; a.bias = bias; a.cu = cu_seqlens; a.out = out; a.n_head = n_head;
+    a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.out = out; a.n_head = n_head;
     const int KT = Wqkv.K / 64;
     const size_t lds = (size_t)KT * 16384 + 9 * QA_WSLOT + 2 * QA_TOK * 64 + 32 * QA_VT_LD * 2;
-    static bool configured[7] = {};
+    static bool configured[3][7] = {};
     auto go = [&](auto kernel) {
-        if (!configured[KT]) {
+        if (!configured[Wqkv.type][KT]) {
             (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured[KT] = true;
+            configured[Wqkv.type][KT] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(n_sentences), dim3(512), lds, stream, a);
         TL_DUMP(n_sentences >= 256, 136);
     };
-    switch (KT) {
-        case 1: go(qkv_attention_kernel<1>); break;
-        case 2: go(qkv_attention_kernel<2>); break;
-        case 3: go(qkv_attention_kernel<3>); break;
-        case 4: go(qkv_attention_kernel<4>); break;
-        case 5: go(qkv_attention_kernel<5>); break;
-        default: go(qkv_attention_kernel<6>); break;
+    if (Wqkv.type == GW_F16) {
+        switch (KT) {
+            case 1: go(qkv_attention_kernel<1, GW_F16>); break;
+            case 2: go(qkv_attention_kernel<2, GW_F16>); break;
+            case 3: go(qkv_attention_kernel<3, GW_F16>); break;
+            case 4: go(qkv_attention_kernel<4, GW_F16>); break;
+            case 5: go(qkv_attention_kernel<5, GW_F16>); break;
+            default: go(qkv_attention_kernel<6, GW_F16>); break;
+        }
+    } else if (Wqkv.type == GW_Q4_0) {
+        switch (KT) {
+            case 2: go(qkv_attention_kernel<2, GW_Q4_0>); break;
+            case 4: go(qkv_attention_kernel<4, GW_Q4_0>); break;
+            default: go(qkv_attention_kernel<6, GW_Q4_0>); break;
+        }
+    } else {
+        switch (KT) {
+            case 2: go(qkv_attention_kernel<2, GW_Q4_1>); break;
+            case 4: go(qkv_attention_kernel<4, GW_Q4_1>); break;
+            default: go(qkv_attention_kernel<6, GW_Q4_1>); break;
+        }
     }
 }
 

@@ -221,6 +221,31 @@ def test_qkv_attention_fused_kernel(n_head, lens):
     assert err.max() < 6e-3, (n_head, lens, float(err.max()))
 
 
+@pytest.mark.parametrize("wtype", [2, 3])
+@pytest.mark.parametrize("n_head,lens", [(4, [128, 1, 77, 5]), (8, [33, 128, 64] * 3), (12, [128, 2, 99, 31, 128])])
+def test_qkv_attention_fused_kernel_q4(n_head, lens, wtype):
+    """q4_0 / q4_1 weights in the fused kernel: blocks fetched to registers and dequantised into the projection waves'
+    private tiles — the same dequantisation and accumulation order as the panel kernel (equal bits), and within f16
+    rounding of a float64 reference computed from the dequantised weights (oracle rule, reference ggml.c:734-790)."""
+    d_head, H = 32, 32 * n_head
+    rng = np.random.default_rng(sum(lens) + n_head + wtype)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    x = rng.normal(0, 1, (T, H)).astype(np.float16)
+    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float32)
+    W[:H] *= 1.7
+    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
+    q = gf.quantize_q4_0(W) if wtype == 2 else gf.quantize_q4_1(W)
+    Wd = (gf.dequantize_q4_0(q) if wtype == 2 else gf.dequantize_q4_1(q)).reshape(W.shape)
+    fused = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, True)
+    split = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, False)
+    assert np.array_equal(fused.view(np.uint16), split.view(np.uint16))
+    qkv = (x.astype(np.float64) @ Wd.astype(np.float64).T + bias).astype(np.float16)
+    want = _attention_ref(qkv, cu, n_head, d_head)
+    err = np.abs(fused.astype(np.float64) - want)
+    assert err.max() < 1e-2, (n_head, lens, float(err.max()))
+
+
 def test_qkv_attention_fused_kernel_limits():
     rng = np.random.default_rng(0)
     H = 128
@@ -230,9 +255,11 @@ def test_qkv_attention_fused_kernel_limits():
     cu = np.array([0, 130], np.int32)
     with pytest.raises(RuntimeError, match="-2"):                      # longer than one workgroup's 128 tokens
         pybert.test_qkv_attention(x, cu, 4, 32, W.astype(np.float16).view(np.uint8), 1, bias, True)
-    q = gf.quantize_q4_0(W)
-    with pytest.raises(RuntimeError, match="-2"):                      # f16 weights only
-        pybert.test_qkv_attention(x[:64], np.array([0, 64], np.int32), 4, 32, q.view(np.uint8), 2, bias, True)
+    H = 192
+    q = gf.quantize_q4_0(rng.normal(0, 0.1, (3 * H, H)).astype(np.float32))
+    with pytest.raises(RuntimeError, match="-2"):                      # q4: an even number of 64-wide k-tiles only
+        pybert.test_qkv_attention(rng.normal(0, 1, (64, H)).astype(np.float16), np.array([0, 64], np.int32), 6, 32,
+                                  q.view(np.uint8), 2, np.zeros(3 * H, np.float32), True)
 
 
 def test_attention_generic_head_dim():
