@@ -33,6 +33,12 @@ namespace {
 
 constexpr int LT_TILE = 16384;
 
+#ifndef LT_SPREAD
+#define LT_SPREAD 1
+#endif
+#ifndef LT_PIN
+#define LT_PIN 1
+#endif
 struct TailArgs {
     const half_t *ctx, *x;            // [T_pad][H]
     const half_t *wo;                 // [H_pad][H] f16
@@ -59,6 +65,55 @@ __device__ __forceinline__ void wait_lgkm12(f16x8 (&f)[8], f16x8 (&y)[4]) {
     asm volatile("s_waitcnt lgkmcnt(12)"
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
                    "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : : "memory");
+}
+// GELU filler placement: the 16 element pairs of gelu(c+1) sit behind the MFMAs of the NT intervals of DOWN(c); the
+// first 8 MFMAs of interval 0 still finish UP(c+1), which leaves 8 + (NT-1)*16 usable slots.  Pair q sits at usable
+// slot floor(q * total / 16).  lt_pair_of: the pair at MFMA slot `slot16` (0..15) of interval d, or -1;
+// lt_pair_rank: how many pairs sit in slots grp*8 .. grp*8+k-1 of that interval.
+template <int NT>
+constexpr int lt_pair_of(int d, int slot16) {
+    static_assert(NT >= 2, "16 pairs need at least 16 usable slots");
+    const int first = d == 0 ? 8 : 0, before = d == 0 ? 0 : 8 + (d - 1) * 16, total = 8 + (NT - 1) * 16;
+    if (slot16 < first) return -1;
+    const int u = before + slot16 - first;
+    const int q = (u * 16 + total - 1) / total;               // smallest q with q * total / 16 >= u
+    return (q < 16 && (q * total) / 16 == u) ? q : -1;
+}
+template <int NT>
+constexpr int lt_pair_rank(int d, int grp, int k) {
+    int n = 0;
+    for (int kk = 0; kk < k; ++kk) n += lt_pair_of<NT>(d, grp * 8 + kk) >= 0;
+    return n;
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ f32x2 lds_read_b64_u(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// hands N hand-read bias pairs to their users; WAIT: after retiring everything but the newest 8 LDS reads
+// (every operand names a different register pair: a repeated operand would be COPIED before the asm, i.e. before its
+// read has landed)
+#define LT_FENCE(TEXT, ...) asm volatile(TEXT : __VA_ARGS__ : : "memory")
+template <int N, bool WAIT>
+__device__ __forceinline__ void bias_fence_n(f32x2 (&b)[6]) {
+    static_assert(N >= 0 && N <= 6, "");
+    if constexpr (WAIT) {
+        if constexpr (N == 1) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]));
+        if constexpr (N == 2) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]));
+        if constexpr (N == 3) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+        if constexpr (N == 4) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        if constexpr (N == 5) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+        if constexpr (N == 6) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
+    } else {
+        if constexpr (N == 1) LT_FENCE("", "+v"(b[0]));
+        if constexpr (N == 2) LT_FENCE("", "+v"(b[0]), "+v"(b[1]));
+        if constexpr (N == 3) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
+        if constexpr (N == 4) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+        if constexpr (N == 5) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
+        if constexpr (N == 6) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
+    }
 }
 // tile barrier: this wave's share of the next tile has landed (all but the newest VM pieces), every hand-issued
 // read has returned (the second-half fragments are named: their MFMAs run after the barrier)
@@ -130,22 +185,30 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     };
     lane_offsets(lane);
     const half_t *const wo = a.wo, *const w1p = a.w1p, *const w2p = a.w2p;     // (locals: keeps the argument struct out of scratch)
-    auto dma128 = [&](const half_t *base, unsigned oe, unsigned oo, int row_bytes, int slot) __attribute__((always_inline)) {
+    // PC = piece of this wave to request (0..3), or -1 for all four
+    using ALLP = std::integral_constant<int, -1>;
+    auto dma128 = [&](const half_t *base, unsigned oe, unsigned oo, int row_bytes, int slot, auto pc_tag) __attribute__((always_inline)) {
+        constexpr int PC = decltype(pc_tag)::value;
         char *dst = ring + slot * LT_TILE + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 8 * row_bytes + ((i & 1) ? oo : oe)),
-                                             AS_LDS(dst + i * 1024), 16, 0, 0);
+        static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (PC < 0 || PC == i)
+                __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 8 * row_bytes + ((i & 1) ? oo : oe)),
+                                                 AS_LDS(dst + i * 1024), 16, 0, 0);
+        });
     };
-    auto dma_proj = [&](int n3, int kt, int slot) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offHe, offHo, H * 2, slot); };
-    auto dma_down = [&](int c, int n3, int slot) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offIe, offIo, I * 2, slot); };
-    auto dma_up = [&](int c, int j, int slot) __attribute__((always_inline)) {
+    auto dma_proj = [&](int n3, int kt, int slot, auto pc) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offHe, offHo, H * 2, slot, pc); };
+    auto dma_down = [&](int c, int n3, int slot, auto pc) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offIe, offIo, I * 2, slot, pc); };
+    auto dma_up = [&](int c, int j, int slot, auto pc_tag) __attribute__((always_inline)) {
+        constexpr int PC = decltype(pc_tag)::value;
         const half_t *base = w1p + (size_t)c * 64 * H + j * 128;
         char *dst = ring + slot * LT_TILE + wave * 4096;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 4 * H * 2 + (offUb + (offUx ^ (unsigned)(i << 6)))),
-                                             AS_LDS(dst + i * 1024), 16, 0, 0);
+        static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value;
+            if constexpr (PC < 0 || PC == i)
+                __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 4 * H * 2 + (offUb + (offUx ^ (unsigned)(i << 6)))),
+                                                 AS_LDS(dst + i * 1024), 16, 0, 0);
+        });
     };
 
     // ---- per-lane LDS addresses
@@ -154,6 +217,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     unsigned aA0 = lds_addr(ring) + off64(l31, hi);                                   // [128 x 64]: + ob * 4 KiB + slot * 16 KiB
     unsigned aU0 = lds_addr(ring) + l31 * 256 + ((hi ^ (l31 & 15)) << 4);            // [64 x 128]: + fb * 8 KiB + slot * 16 KiB
     unsigned aY = lds_addr(S) + lane * 16;                    // y fragment q at + q * 1 KiB
+    unsigned aB = lds_addr(cb1) + hi * 16;                    // up-projection biases of a lane's features: + chunk * 256 B
 
     f32x16 acc2[NB], accU[2];
     f16x8 g[2][4];                                            // GELU'ed chunks (two in flight) as B fragments
@@ -229,22 +293,44 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     // One interval = one tile.  On entry the tile is complete in LDS for every wave.  `prev` = the tile whose second
     // half is still owed (NoTile after a drain), `prefetch(slot)` requests tile +2, `filler(group, k)` is VALU work
     // issued behind the k-th MFMA of the owed half (group 0) / of this tile's first half (group 1), VM = DMA pieces of this wave that may stay in flight at the closing barrier.
-    auto interval = [&](auto cur, auto prev, auto vm_tag, auto &&prefetch, auto &&filler) __attribute__((always_inline)) {
+    auto interval = [&](auto cur, auto prev, auto vm_tag, auto &&prefetch, auto &&filler, auto &&pre, auto &&fence) __attribute__((always_inline)) {
         using C = decltype(cur);
         using P = decltype(prev);
         constexpr int VM = decltype(vm_tag)::value;
         const unsigned so = (unsigned)slot * LT_TILE;
         TL_STAMP(tl++);
+        const int pslot = slot == 0 ? 2 : slot - 1;           // slot + 2 (mod 3): read one tile ago, free since the barrier
+        // pre(group) issues the LDS reads the fillers of that group need (by hand, like the fragments: a compiler-issued
+        // read is retired with lgkmcnt(0), which would wait for every fragment read in flight); fence(group) hands them over
+        pre(H0{});
         read_half(cur, H0{}, so);
-        prefetch(slot == 0 ? 2 : slot - 1);                   // slot + 2 (mod 3): read one tile ago, free since the barrier
+        fence(H0{});
+#if LT_SPREAD
+        // the 4 DMA pieces go behind MFMAs 1, 3, 5, 7 of the owed half (a piece costs >= 60 issue cycles, an MFMA covers 32)
+        if constexpr (P::kind != K_NONE)
+            mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) {
+                constexpr int kk = decltype(k)::value;
+                if constexpr (kk & 1) prefetch(pslot, std::integral_constant<int, (kk >> 1)>{});
+                filler(H0{}, k);
+            });
+        else prefetch(pslot, ALLP{});
+#else
+        prefetch(pslot, ALLP{});
         if constexpr (P::kind != K_NONE) mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) { filler(H0{}, k); });
+#endif
+        pre(H1{});
         read_half(cur, H1{}, so);
         if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
+        fence(H1{});
         mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) { filler(H1{}, k); });
+#if LT_PIN
+        __builtin_amdgcn_sched_barrier(0);                    // the first-half MFMAs cover the second-half reads: keep them above the barrier
+#endif
         tile_barrier<VM>(F[1], Y[1]);
         slot = slot == 2 ? 0 : slot + 1;
     };
     auto nothing = [](auto, auto) __attribute__((always_inline)) {};
+    auto nothing1 = [](auto) __attribute__((always_inline)) {};
     auto drain = [&](auto prev) __attribute__((always_inline)) { mma_half(prev, H1{}, [](auto) __attribute__((always_inline)) {}); };
     using VM4 = std::integral_constant<int, 4>;
     using VM0 = std::integral_constant<int, 0>;
@@ -252,12 +338,9 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     // GELU of fragment j (features 32*(j>>1) + 16*(j&1) .. +16 of chunk c) of the up-projection accumulators into
     // g[par], in four steps of two elements so that it can be spread behind the MFMAs of an interval (a wave's VALU work
     // only overlaps its own MFMAs if it is issued between them)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    auto gelu_pair = [&](auto par_tag, auto j_tag, auto p_tag, int c) __attribute__((always_inline)) {
+    auto gelu_pair = [&](auto par_tag, auto j_tag, auto p_tag, f32x2 b) __attribute__((always_inline)) {
         constexpr int par = decltype(par_tag)::value, j = decltype(j_tag)::value, fb = j >> 1, s = j & 1;
         constexpr int p = decltype(p_tag)::value;             // elements 2p, 2p+1 of the fragment = registers 8s + 2p, +1
-        // their features: 32fb + 16s + 4hi + {2p, 2p+1} (p < 2) or + 8 + {2p-4, 2p-3}
-        const f32x2 b = *(const f32x2 *)(cb1 + c * 64 + 32 * fb + 16 * s + 4 * hi + (p < 2 ? 2 * p : 4 + 2 * p));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             constexpr int e0 = 2 * p;
@@ -266,22 +349,47 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             accU[fb][8 * s + e0 + t] = 0.f;
         }
     };
+    // bias of pair (j, p) of a chunk: features 32fb + 16s + 4hi + {2p, 2p+1} (p < 2) or + 8 + {2p-4, 2p-3}, as a float offset
+    // into the chunk's 64 biases without the 4hi part
+    auto bias_off = [](int j, int p) constexpr { return 32 * (j >> 1) + 16 * (j & 1) + (p < 2 ? 2 * p : 4 + 2 * p); };
 
     // ================================ out-projection ================================
-    dma_proj(0, 0, 0);
-    if (NT * KU > 1) dma_proj(KU > 1 ? 0 : 1, KU > 1 ? 1 : 0, 1);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // x rows, ctx fragments, tiles 0 and 1
+    dma_proj(0, 0, 0, ALLP{});
+    if (NT * KU > 1) dma_proj(KU > 1 ? 0 : 1, KU > 1 ? 1 : 0, 1, ALLP{});
+#ifndef LT_PREFETCH
+#define LT_PREFETCH 0
+#endif
+    // L2 warm-up.  Every workgroup streams the same 3 matrices in the same order and the workgroups of an XCD run in
+    // step, so without help each tile's first touch is a miss that ALL of them wait for (the ring holds two tiles in
+    // flight: interval >= miss latency / 2).  The workgroups of an XCD (blockIdx % 8, 32 of them on a full chip) each
+    // touch 1/32 of the layer's weight lines once, after their activation loads, so that the tile stream finds
+    // them in that XCD's L2 (2.6 MB of 4 MB).
+    unsigned warm = 0;
+    if (LT_PREFETCH && gridDim.x >= 64) {
+        const int nsh = gridDim.x >= 256 ? 32 : (int)(gridDim.x >> 3);
+        const int j = (int)(blockIdx.x >> 3) % nsh;
+        auto touch = [&](const half_t *base, int nlines) __attribute__((always_inline)) {
+            const int per = (nlines + nsh - 1) / nsh;
+            const int l1 = min(nlines, (j + 1) * per);
+            for (int l = j * per + tid; l < l1; l += 256)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(warm) : "v"((const char *)base + (size_t)l * 128));
+        };
+        touch(a.wo, H * H / 64);
+        touch(a.w1p, I * (H / 64));
+        touch(a.w2p, I * (H / 64));
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(warm) : : "memory");     // x rows, ctx fragments, tiles 0 and 1
     static_for<NT * KU>([&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value, n3 = t / KU, kt = t % KU;
         using Cur = TileDesc<K_PROJ, n3, kt>;
         using Prev = std::conditional_t<t == 0, NoTile, TileDesc<K_PROJ, (t - 1) / KU, (t - 1) % KU>>;
         // tile t+2: still out-projection, or the first up-projection tiles of chunk 0
-        auto pf = [&](int s2) __attribute__((always_inline)) {
+        auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
             constexpr int t2 = t + 2;
-            if constexpr (t2 < NT * KU) dma_proj(t2 / KU, t2 % KU, s2);
-            else dma_up(0, t2 - NT * KU, s2);                 // up-projection tiles 0, 1 of chunk 0 (NT >= 2), see below
+            if constexpr (t2 < NT * KU) dma_proj(t2 / KU, t2 % KU, s2, pc);
+            else dma_up(0, t2 - NT * KU, s2, pc);                 // up-projection tiles 0, 1 of chunk 0 (NT >= 2), see below
         };
-        interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+        interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
     });
     drain(TileDesc<K_PROJ, NT - 1, KU - 1>{});
 
@@ -348,6 +456,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         aA0 = lds_addr(ring) + off64(l31e, hie);
         aU0 = lds_addr(ring) + l31e * 256 + ((hie ^ (l31e & 15)) << 4);
         aY = lds_addr(S) + lane_e * 16;
+        aB = lds_addr(cb1) + hie * 16;
     };
     refresh_lane_values();
 #pragma unroll
@@ -367,67 +476,78 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         constexpr int j = decltype(j_tag)::value;
         using Cur = TileDesc<K_UP, 0, j>;
         using Prev = std::conditional_t<j == 0, NoTile, TileDesc<K_UP, 0, j - 1>>;
-        auto pf = [&](int s2) __attribute__((always_inline)) {
+        auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
             constexpr int j2 = j + 2;
-            if constexpr (j2 < NT) dma_up(0, j2, s2); else dma_up(1, j2 - NT, s2);
+            if constexpr (j2 < NT) dma_up(0, j2, s2, pc); else dma_up(1, j2 - NT, s2, pc);
         };
-        interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+        interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
     });
     drain(TileDesc<K_UP, 0, NT - 1>{});
     static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
-        static_for<4>([&](auto p_tag) __attribute__((always_inline)) { gelu_pair(H0{}, j_tag, p_tag, 0); });
+        static_for<4>([&](auto p_tag) __attribute__((always_inline)) {
+            gelu_pair(H0{}, j_tag, p_tag, *(const f32x2 *)(cb1 + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
+        });
     });
 
     // ---- step c: UP(c+1), then DOWN(c) with gelu(c+1) as filler.  GP = c & 1 (g buffer of chunk c).
-    auto step = [&](auto gp_tag, auto first_tag, int c) __attribute__((always_inline)) {
+    // FIRST: c == 0; LAST: c == NC - 2 (no UP(c+2) to request: a separate instantiation keeps the requests branch-free)
+    auto step = [&](auto gp_tag, auto first_tag, auto last_tag, int c) __attribute__((always_inline)) {
         constexpr int GP = decltype(gp_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
         static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value;
             using Cur = TileDesc<K_UP, 0, j>;
             // owed on entry: nothing after the exposed gelu(0), else the last tile of DOWN(c-1)
             using Entry = std::conditional_t<FIRST, NoTile, TileDesc<K_DOWN, GP ^ 1, NT - 1>>;
             using Prev = std::conditional_t<j == 0, Entry, TileDesc<K_UP, 0, j - 1>>;
-            auto pf = [&](int s2) __attribute__((always_inline)) {
+            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
                 constexpr int j2 = j + 2;
-                if constexpr (j2 < NT) dma_up(c + 1, j2, s2); else dma_down(c, j2 - NT, s2);
+                if constexpr (j2 < NT) dma_up(c + 1, j2, s2, pc); else dma_down(c, j2 - NT, s2, pc);
             };
-            interval(Cur{}, Prev{}, VM4{}, pf, nothing);
+            interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
         });
         static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
             constexpr int d = decltype(d_tag)::value;
             using Cur = TileDesc<K_DOWN, GP, d>;
             using Prev = std::conditional_t<d == 0, TileDesc<K_UP, 0, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
-            auto pf = [&](int s2) __attribute__((always_inline)) {
+            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
                 constexpr int d2 = d + 2;
-                if constexpr (d2 < NT) dma_down(c, d2, s2);
-                else if (c + 2 < NC) dma_up(c + 2, d2 - NT, s2);
-                else dma_down(c + 1, d2 - NT, s2);            // chunk c+1 is the last one: only its DOWN tiles are left
+                if constexpr (d2 < NT) dma_down(c, d2, s2, pc);
+                else if constexpr (!LAST) dma_up(c + 2, d2 - NT, s2, pc);
+                else dma_down(c + 1, d2 - NT, s2, pc);        // chunk c+1 is the last one: only its DOWN tiles are left
             };
-            // the 16 element pairs of gelu(c+1) behind the MFMAs of the NT intervals: pair q -> interval q / PPI, slot
-            // (q % PPI) * (16 / PPI) of its 16 MFMAs.  The first MFMAs of interval 0 finish UP(c+1): no pair before slot 8.
+            // the 16 element pairs of gelu(c+1) behind the MFMAs of the NT intervals (lt_pair_of); their biases are read
+            // by hand one group of 8 MFMA slots ahead
+            f32x2 Bv[2][6];
+            const unsigned aBc = aB + (unsigned)(c + 1) * 256u;
+            auto pre = [&](auto grp_tag) __attribute__((always_inline)) {
+                constexpr int grp = decltype(grp_tag)::value;
+                static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
+                    constexpr int k = decltype(k_tag)::value, q = lt_pair_of<NT>(d, grp * 8 + k);
+                    if constexpr (q >= 0) Bv[grp][lt_pair_rank<NT>(d, grp, k)] = lds_read_b64_u<bias_off(q / 4, q % 4) * 4>(aBc);
+                });
+            };
+            auto fence = [&](auto grp_tag) __attribute__((always_inline)) {
+                constexpr int grp = decltype(grp_tag)::value;
+                bias_fence_n<lt_pair_rank<NT>(d, grp, 8), grp == 0>(Bv[grp]);
+            };
             auto fill = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
-                constexpr int slot16 = decltype(grp_tag)::value * 8 + decltype(k_tag)::value;
-                constexpr int first = d == 0 ? 8 : 0;                                     // usable slots of this interval
-                constexpr int before = d == 0 ? 0 : 8 + (d - 1) * 16;                     // usable slots of earlier intervals
-                constexpr int total = 8 + (NT - 1) * 16;
-                if constexpr (slot16 >= first) {
-                    // pairs are spread evenly over the usable slots: pair q sits at usable slot floor(q * total / 16)
-                    constexpr int u = before + slot16 - first;
-                    constexpr int q = (u * 16 + total - 1) / total;                        // smallest q with q * total / 16 >= u
-                    if constexpr (q < 16 && (q * total) / 16 == u)
-                        gelu_pair(std::integral_constant<int, GP ^ 1>{}, std::integral_constant<int, q / 4>{},
-                                  std::integral_constant<int, q % 4>{}, c + 1);
-                }
+                constexpr int grp = decltype(grp_tag)::value, k = decltype(k_tag)::value, q = lt_pair_of<NT>(d, grp * 8 + k);
+                if constexpr (q >= 0)
+                    gelu_pair(std::integral_constant<int, GP ^ 1>{}, std::integral_constant<int, q / 4>{},
+                              std::integral_constant<int, q % 4>{}, Bv[grp][lt_pair_rank<NT>(d, grp, k)]);
             };
-            interval(Cur{}, Prev{}, VM4{}, pf, fill);
+            interval(Cur{}, Prev{}, VM4{}, pf, fill, pre, fence);
         });
     };
-    step(H0{}, std::true_type{}, 0);
-    for (int c = 1; c + 1 < NC; c += 2) {
-        step(H1{}, std::false_type{}, c);
-        if (c + 2 < NC) step(H0{}, std::false_type{}, c + 1);
+    // NC is even and >= 4: steps c = 0 .. NC-2 (GP = c & 1), the last one with GP = 0
+    step(H0{}, std::true_type{}, std::false_type{}, 0);
+    for (int c = 1; c + 3 < NC; c += 2) {
+        step(H1{}, std::false_type{}, std::false_type{}, c);
+        step(H0{}, std::false_type{}, std::false_type{}, c + 1);
     }
+    step(H1{}, std::false_type{}, std::false_type{}, NC - 3);
+    step(H0{}, std::false_type{}, std::true_type{}, NC - 2);
     // ---- DOWN(NC-1)
     auto last_down = [&](auto gp_tag) __attribute__((always_inline)) {
         constexpr int GP = decltype(gp_tag)::value;
@@ -435,16 +555,16 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             constexpr int d = decltype(d_tag)::value;
             using Cur = TileDesc<K_DOWN, GP, d>;
             using Prev = std::conditional_t<d == 0, TileDesc<K_DOWN, GP ^ 1, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
-            auto pf = [&](int s2) __attribute__((always_inline)) {
+            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
                 constexpr int d2 = d + 2;
-                if constexpr (d2 < NT) dma_down(NC - 1, d2, s2);
+                if constexpr (d2 < NT) dma_down(NC - 1, d2, s2, pc);
             };
             constexpr int vm = d + 2 < NT ? 4 : 0;
-            interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing);
+            interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing, nothing1, nothing1);
         });
         drain(TileDesc<K_DOWN, GP, NT - 1>{});
     };
-    if ((NC - 1) & 1) last_down(H1{}); else last_down(H0{});
+    last_down(H1{});                                          // NC - 1 is odd
 
     // ================================ LayerNorm 2 (wave-local) -> rows in S -> HBM ================================
     TL_STAMP(tl++);
@@ -521,7 +641,7 @@ bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gemm
     const int H = W1.K, I = W1.N;
     if (Wo.type != GW_F16 || W1.type != GW_F16 || W2.type != GW_F16 || !W1.w16p || !W2.w16p) return false;
     if (Wo.N != H || Wo.K != H || W2.N != H || W2.K != I) return false;
-    if (H % 128 != 0 || H < 256 || H > 384 || I % 64 != 0 || I < 128) return false;
+    if (H % 128 != 0 || H < 256 || H > 384 || I % 128 != 0 || I < 256) return false;     // an even number >= 4 of 64-feature chunks
     const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + I) * sizeof(float);
     return lds <= 160 * 1024;
 }
@@ -544,7 +664,6 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
         TL_DUMP(M_pad >= 128 * 256, 200);
     };
     switch (NT) {
-        case 1: go(layer_tail_kernel<1>); break;
         case 2: go(layer_tail_kernel<2>); break;
         default: go(layer_tail_kernel<3>); break;
     }
