@@ -33,11 +33,10 @@ namespace {
 
 constexpr int LT_TILE = 16384;
 
-#ifndef LT_SPREAD
-#define LT_SPREAD 1
-#endif
-#ifndef LT_PIN
-#define LT_PIN 1
+// LT_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no GELU arithmetic, bit 2 no tile barrier,
+// bit 3 no fragment reads, bit 4 no MFMAs — what a component costs is the time its removal saves (tools/variant.sh)
+#ifndef LT_ABLATE
+#define LT_ABLATE 0
 #endif
 struct TailArgs {
     const half_t *ctx, *x;            // [T_pad][H]
@@ -119,7 +118,12 @@ __device__ __forceinline__ void bias_fence_n(f32x2 (&b)[6]) {
 // read has returned (the second-half fragments are named: their MFMAs run after the barrier)
 template <int VM>
 __device__ __forceinline__ void tile_barrier(f16x8 (&f)[8], f16x8 (&y)[4]) {
-    asm volatile("s_waitcnt vmcnt(%12) lgkmcnt(0)\n\ts_barrier"
+#if LT_ABLATE & 4
+#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(0)"
+#else
+#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(0)\n\ts_barrier"
+#endif
+    asm volatile(LT_BARRIER_TEXT
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
                    "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "n"(VM) : "memory");
 }
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         char *dst = ring + slot * LT_TILE + wave * 4096;
         static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
             constexpr int i = decltype(i_tag)::value;
-            if constexpr (PC < 0 || PC == i)
+            if constexpr ((PC < 0 || PC == i) && !(LT_ABLATE & 1))
                 __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 8 * row_bytes + ((i & 1) ? oo : oe)),
                                                  AS_LDS(dst + i * 1024), 16, 0, 0);
         });
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         char *dst = ring + slot * LT_TILE + wave * 4096;
         static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
             constexpr int i = decltype(i_tag)::value;
-            if constexpr (PC < 0 || PC == i)
+            if constexpr ((PC < 0 || PC == i) && !(LT_ABLATE & 1))
                 __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 4 * H * 2 + (offUb + (offUx ^ (unsigned)(i << 6)))),
                                                  AS_LDS(dst + i * 1024), 16, 0, 0);
         });
@@ -239,7 +243,8 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     auto read_half = [&](auto desc, auto half_tag, unsigned slot_off) __attribute__((always_inline)) {
         using D = decltype(desc);
         constexpr int half = decltype(half_tag)::value;
-        if constexpr (D::kind == K_UP) {
+        if constexpr (LT_ABLATE & 8) {
+        } else if constexpr (D::kind == K_UP) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const unsigned ad = (aU0 ^ (unsigned)((half * 4 + i) << 5)) + slot_off;
@@ -267,7 +272,9 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         using D = decltype(desc);
         constexpr int half = decltype(half_tag)::value;
         // fill(k): VALU filler issued behind the k-th MFMA of the half (k = 0..7), in program order
-        if constexpr (D::kind == K_UP) {
+        if constexpr (LT_ABLATE & 16) {
+            static_for<8>([&](auto k_tag) __attribute__((always_inline)) { fill(k_tag); });
+        } else if constexpr (D::kind == K_UP) {
             static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
                 constexpr int k = decltype(k_tag)::value, i = k >> 1, fb = k & 1;
                 accU[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][fb * 4 + i], Y[half][i], accU[fb], 0, 0, 0);
@@ -305,7 +312,6 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         pre(H0{});
         read_half(cur, H0{}, so);
         fence(H0{});
-#if LT_SPREAD
         // the 4 DMA pieces go behind MFMAs 1, 3, 5, 7 of the owed half (a piece costs >= 60 issue cycles, an MFMA covers 32)
         if constexpr (P::kind != K_NONE)
             mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) {
@@ -314,18 +320,14 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
                 filler(H0{}, k);
             });
         else prefetch(pslot, ALLP{});
-#else
-        prefetch(pslot, ALLP{});
-        if constexpr (P::kind != K_NONE) mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) { filler(H0{}, k); });
-#endif
         pre(H1{});
         read_half(cur, H1{}, so);
         if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
         fence(H1{});
         mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) { filler(H1{}, k); });
-#if LT_PIN
-        __builtin_amdgcn_sched_barrier(0);                    // the first-half MFMAs cover the second-half reads: keep them above the barrier
-#endif
+        // the first-half MFMAs cover the second-half reads; left alone the scheduler sinks them below the barrier, whose
+        // lgkmcnt(0) then waits for those reads with an empty matrix pipe
+        __builtin_amdgcn_sched_barrier(0);
         tile_barrier<VM>(F[1], Y[1]);
         slot = slot == 2 ? 0 : slot + 1;
     };
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         for (int t = 0; t < 2; ++t) {
             constexpr int e0 = 2 * p;
             const float xv = accU[fb][8 * s + e0 + t] + b[t];
-            g[par][j][e0 + t] = (_Float16)gelu_fast(xv);
+            g[par][j][e0 + t] = (LT_ABLATE & 2) ? (_Float16)xv : (_Float16)gelu_fast(xv);
             accU[fb][8 * s + e0 + t] = 0.f;
         }
     };
@@ -356,29 +358,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     // ================================ out-projection ================================
     dma_proj(0, 0, 0, ALLP{});
     if (NT * KU > 1) dma_proj(KU > 1 ? 0 : 1, KU > 1 ? 1 : 0, 1, ALLP{});
-#ifndef LT_PREFETCH
-#define LT_PREFETCH 0
-#endif
-    // L2 warm-up.  Every workgroup streams the same 3 matrices in the same order and the workgroups of an XCD run in
-    // step, so without help each tile's first touch is a miss that ALL of them wait for (the ring holds two tiles in
-    // flight: interval >= miss latency / 2).  The workgroups of an XCD (blockIdx % 8, 32 of them on a full chip) each
-    // touch 1/32 of the layer's weight lines once, after their activation loads, so that the tile stream finds
-    // them in that XCD's L2 (2.6 MB of 4 MB).
-    unsigned warm = 0;
-    if (LT_PREFETCH && gridDim.x >= 64) {
-        const int nsh = gridDim.x >= 256 ? 32 : (int)(gridDim.x >> 3);
-        const int j = (int)(blockIdx.x >> 3) % nsh;
-        auto touch = [&](const half_t *base, int nlines) __attribute__((always_inline)) {
-            const int per = (nlines + nsh - 1) / nsh;
-            const int l1 = min(nlines, (j + 1) * per);
-            for (int l = j * per + tid; l < l1; l += 256)
-                asm volatile("global_load_dword %0, %1, off" : "+v"(warm) : "v"((const char *)base + (size_t)l * 128));
-        };
-        touch(a.wo, H * H / 64);
-        touch(a.w1p, I * (H / 64));
-        touch(a.w2p, I * (H / 64));
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(warm) : : "memory");     // x rows, ctx fragments, tiles 0 and 1
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // x rows, ctx fragments, tiles 0 and 1
     static_for<NT * KU>([&](auto t_tag) __attribute__((always_inline)) {
         constexpr int t = decltype(t_tag)::value, n3 = t / KU, kt = t % KU;
         using Cur = TileDesc<K_PROJ, n3, kt>;
