@@ -80,10 +80,16 @@ private:
 
     // workspace (grow-only)
     DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_;
-    int32_t *h_tokens_ = nullptr, *h_cu_ = nullptr;   // pinned staging
-    float *h_out_ = nullptr;
-    size_t h_tokens_cap_ = 0, h_cu_cap_ = 0, h_out_cap_ = 0;
     hipStream_t stream_ = nullptr;
+    // host path: two sets of pinned staging + device id / embedding buffers, so that the host stages chunk i+1 and
+    // unpacks chunk i-1 while the GPU computes chunk i (eval_packed_host)
+    struct HostSlot {
+        int32_t *h_tokens = nullptr, *h_cu = nullptr;
+        float *h_out = nullptr;
+        size_t h_tokens_cap = 0, h_cu_cap = 0, h_out_cap = 0;
+        DevBuf d_tokens, d_cu, d_out;
+        hipEvent_t done = nullptr;
+    } slot_[2];
 
     // options
     bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, tail_ = true, q4_expand_ = true;

@@ -237,9 +237,12 @@ Engine::~Engine() {
     for (auto *L : layers_) delete L;
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     for (auto &p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
-    if (h_tokens_) (void)hipHostFree(h_tokens_);
-    if (h_cu_) (void)hipHostFree(h_cu_);
-    if (h_out_) (void)hipHostFree(h_out_);
+    for (auto &sl : slot_) {
+        if (sl.h_tokens) (void)hipHostFree(sl.h_tokens);
+        if (sl.h_cu) (void)hipHostFree(sl.h_cu);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -406,30 +409,61 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     if (B <= 0) return 0;
     HIP_OK(hipSetDevice(device_), err, -1);
     const int H = hp_.n_embd;
-    int b0 = 0;
-    while (b0 < B) {
-        // chunk [b0, b1): at most chunk_tokens_ tokens, at least one sentence
+    // chunks [b0, b1): at most chunk_tokens_ tokens, at least one sentence
+    struct Chunk { int b0, b1, max_len; };
+    std::vector<Chunk> chunks;
+    size_t max_T = 0, max_nb = 0;
+    for (int b0 = 0; b0 < B;) {
         int b1 = b0 + 1, max_len = cu[b0 + 1] - cu[b0];
         while (b1 < B && cu[b1 + 1] - cu[b0] <= chunk_tokens_) { max_len = std::max(max_len, cu[b1 + 1] - cu[b1]); ++b1; }
-        const int nb = b1 - b0, T = cu[b1] - cu[b0];
-        if (!ensure_pinned((void **)&h_tokens_, &h_tokens_cap_, (size_t)T * 4, err)) return -1;
-        if (!ensure_pinned((void **)&h_cu_, &h_cu_cap_, (size_t)(nb + 1) * 4, err)) return -1;
-        if (!ensure_pinned((void **)&h_out_, &h_out_cap_, (size_t)nb * H * 4, err)) return -1;
-        if (!d_tokens_.ensure((size_t)T * 4, err) || !d_cu_.ensure((size_t)(nb + 1) * 4, err)) return -1;
-        memcpy(h_tokens_, tokens + cu[b0], (size_t)T * 4);
-        for (int i = 0; i <= nb; ++i) h_cu_[i] = cu[b0 + i] - cu[b0];
-        const int t_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
-        if (!ensure_workspace(t_pad, nb, err)) return -1;
-        HIP_OK(hipMemcpyAsync(d_tokens_.p, h_tokens_, (size_t)T * 4, hipMemcpyHostToDevice, stream_), err, -1);
-        HIP_OK(hipMemcpyAsync(d_cu_.p, h_cu_, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_), err, -1);
-        if (eval_packed_device(d_tokens_.as<int32_t>(), d_cu_.as<int32_t>(), nb, T, max_len, d_out_.as<float>(), stream_,
-                               nullptr, err) != 0)
-            return -1;
-        HIP_OK(hipMemcpyAsync(h_out_, d_out_.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_), err, -1);
-        HIP_OK(hipStreamSynchronize(stream_), err, -1);
-        memcpy(embeddings + (size_t)b0 * H, h_out_, (size_t)nb * H * 4);
+        chunks.push_back({b0, b1, max_len});
+        max_T = std::max(max_T, (size_t)(cu[b1] - cu[b0]));
+        max_nb = std::max(max_nb, (size_t)(b1 - b0));
         b0 = b1;
     }
+    // every buffer is sized for the largest chunk BEFORE anything is queued: growing one later would free memory that
+    // a queued chunk still uses
+    const int n_slots = chunks.size() > 1 ? 2 : 1;
+    for (int i = 0; i < n_slots; ++i) {
+        HostSlot &sl = slot_[i];
+        if (!ensure_pinned((void **)&sl.h_tokens, &sl.h_tokens_cap, max_T * 4, err)) return -1;
+        if (!ensure_pinned((void **)&sl.h_cu, &sl.h_cu_cap, (max_nb + 1) * 4, err)) return -1;
+        if (!ensure_pinned((void **)&sl.h_out, &sl.h_out_cap, max_nb * H * 4, err)) return -1;
+        if (!sl.d_tokens.ensure(max_T * 4, err) || !sl.d_cu.ensure((max_nb + 1) * 4, err) || !sl.d_out.ensure(max_nb * H * 4, err)) return -1;
+        if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
+    }
+    if (!ensure_workspace((int)((max_T + GEMM_BM - 1) / GEMM_BM * GEMM_BM), (int)max_nb, err)) return -1;
+
+    // The stream executes H2D, forward, D2H of chunk after chunk; the host runs one chunk ahead: it stages chunk i
+    // into slot i & 1 and queues it, then unpacks chunk i-1 while chunk i computes.
+    auto unpack = [&](size_t i) -> bool {
+        HostSlot &sl = slot_[i & 1];
+        if (hipEventSynchronize(sl.done) != hipSuccess) { err = "hipEventSynchronize failed"; return false; }
+        memcpy(embeddings + (size_t)chunks[i].b0 * H, sl.h_out, (size_t)(chunks[i].b1 - chunks[i].b0) * H * 4);
+        return true;
+    };
+    auto fail = [&]() { (void)hipStreamSynchronize(stream_); return -1; };        // nothing may stay queued on the slots
+    for (size_t i = 0; i < chunks.size(); ++i) {
+        HostSlot &sl = slot_[i & 1];
+        const int b0 = chunks[i].b0, nb = chunks[i].b1 - b0, T = cu[chunks[i].b1] - cu[b0];
+        memcpy(sl.h_tokens, tokens + cu[b0], (size_t)T * 4);
+        for (int j = 0; j <= nb; ++j) sl.h_cu[j] = cu[b0 + j] - cu[b0];
+        if (hipMemcpyAsync(sl.d_tokens.p, sl.h_tokens, (size_t)T * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+            hipMemcpyAsync(sl.d_cu.p, sl.h_cu, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) {
+            err = "hipMemcpyAsync (ids) failed";
+            return fail();
+        }
+        if (eval_packed_device(sl.d_tokens.as<int32_t>(), sl.d_cu.as<int32_t>(), nb, T, chunks[i].max_len, sl.d_out.as<float>(),
+                               stream_, nullptr, err) != 0)
+            return fail();
+        if (hipMemcpyAsync(sl.h_out, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+            hipEventRecord(sl.done, stream_) != hipSuccess) {
+            err = "hipMemcpyAsync (embeddings) failed";
+            return fail();
+        }
+        if (i >= 1 && !unpack(i - 1)) return fail();           // while chunk i computes; frees the slot chunk i+1 stages into
+    }
+    if (!unpack(chunks.size() - 1)) return fail();
     return 0;
 }
 

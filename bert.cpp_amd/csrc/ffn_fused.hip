@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void ffn_fused_kernel(FfnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[n][j][r] = 0.f;
 
-    int tl = 1;
+    [[maybe_unused]] int tl = 1;
     TL_STAMP(0);
     if (PROJ) {
         // ---- leading phase: attention output projection + residual + LayerNorm for the same 128 tokens

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     };
 
     int slot = 0;                                             // ring slot of the current tile
-    int tl = 1;
+    [[maybe_unused]] int tl = 1;
     TL_STAMP(0);
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     auto nothing1 = [](auto) __attribute__((always_inline)) {};
     auto drain = [&](auto prev) __attribute__((always_inline)) { mma_half(prev, H1{}, [](auto) __attribute__((always_inline)) {}); };
     using VM4 = std::integral_constant<int, 4>;
-    using VM0 = std::integral_constant<int, 0>;
+    using VM0 [[maybe_unused]] = std::integral_constant<int, 0>;
 
     // GELU of fragment j (features 32*(j>>1) + 16*(j&1) .. +16 of chunk c) of the up-projection accumulators into
     // g[par], in four steps of two elements so that it can be spread behind the MFMAs of an interval (a wave's VALU work

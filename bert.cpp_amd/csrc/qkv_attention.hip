@@ -239,8 +239,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
         using H1 = std::integral_constant<int, 1>;
 
         int t = 0, slot = 0;
-        int tl = 0;
-        const bool tl_sel = tid == 256;                       // lane 0 of the Q projection wave
+        [[maybe_unused]] int tl = 0;
+        [[maybe_unused]] const bool tl_sel = tid == 256;                       // lane 0 of the Q projection wave
         TL_STAMP_AT(tl_sel, tl++);
         read_half(H0{}, H0{}, 0);                             // tile 0 landed before B0
         for (int h = 0; h <= n_head; ++h) {
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
         const int qb = wave;
         const bool active = qb * 32 < n;
         const float sc = 1.44269504088896340736f / __builtin_sqrtf(32.0f);   // log2(e) / sqrt(d)
-        int tl = 128;
-        const bool tl_sel = tid == 0;
+        [[maybe_unused]] int tl = 128;
+        [[maybe_unused]] const bool tl_sel = tid == 0;
         for (int h = 0; h <= n_head; ++h) {
             if (h < 4) TL_STAMP_AT(tl_sel, tl++);
             if (h > 0 && active) {

@@ -377,6 +377,23 @@ def test_api_equivalences_and_batch_independence(make_model, dims, ftype):
     assert np.array_equal(m.eval_batch(sents), batch)
 
 
+def test_host_path_pipelines_chunks(make_model):
+    """eval_packed_host keeps two chunks in flight (stage / compute / unpack overlap, engine.hip): many chunks of
+    uneven size, buffers growing between calls, a single-chunk call in between — always the bits of the unchunked call."""
+    path, hp = make_model("tiny-h128", "f16", 1)
+    m = pybert.BertModel(path)
+    rng = np.random.default_rng(42)
+    sents = [rng.integers(0, hp.n_vocab, size=int(n)).astype(np.int32) for n in rng.integers(1, hp.n_max_tokens + 1, size=300)]
+    want = m.eval_batch(sents)
+    for chunk in (64, 500, 129, 4096, 70):
+        m.set_option("chunk_tokens", str(chunk))
+        assert np.array_equal(m.eval_batch(sents[:17]), want[:17]), chunk          # small call first: buffers grow afterwards
+        assert np.array_equal(m.eval_batch(sents), want), chunk
+    m2 = pybert.BertModel(path)                                                     # cold context, chunked from the first call
+    m2.set_option("chunk_tokens", "200")
+    assert np.array_equal(m2.eval_batch(sents), want)
+
+
 def test_api_error_behaviour(make_model, capfd):
     path, hp = make_model("tiny", "f16", 1)
     m = pybert.BertModel(path)
