@@ -134,17 +134,17 @@ void bert_tokenize(struct bert_ctx *ctx, const char *text, bert_vocab_id *tokens
     ctx->tok.tokenize(text, tokens, n_tokens, n_max_tokens);
 }
 
-void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batch_size, bert_vocab_id **batch_tokens,
-                     int32_t *n_tokens, float **batch_embeddings) {
-    if (!batch_embeddings) return;   // the reference's memory-probe mode (bert.cpp:739); nothing to size here
-    if (!ctx->engine) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return; }
-    if (n_batch_size <= 0) return;
+// returns the number of sentences evaluated (stops in front of the first one it cannot handle), -1 on a device error
+static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_vocab_id *const *batch_tokens,
+                               const int32_t *n_tokens, float *const *batch_embeddings) {
+    if (!ctx->engine) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
+    if (n_batch_size <= 0) return 0;
     // The reference evaluates sentences in order and stops at the first one it cannot handle,
     // leaving later outputs untouched; keep that observable behaviour.
     int32_t B = 0;
     for (; B < n_batch_size; ++B)
         if (!sentence_ok(ctx, batch_tokens[B], n_tokens[B])) break;
-    if (B == 0) return;
+    if (B == 0) return 0;
     std::vector<int32_t> cu(B + 1, 0);
     for (int32_t b = 0; b < B; ++b) cu[b + 1] = cu[b] + n_tokens[b];
     std::vector<int32_t> packed((size_t)cu[B]);
@@ -154,9 +154,16 @@ void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batc
     std::string err;
     if (ctx->engine->eval_packed_host(packed.data(), cu.data(), B, out.data(), err) != 0) {
         fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
-        return;
+        return -1;
     }
     for (int32_t b = 0; b < B; ++b) memcpy(batch_embeddings[b], out.data() + (size_t)b * H, sizeof(float) * H);
+    return B;
+}
+
+void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batch_size, bert_vocab_id **batch_tokens,
+                     int32_t *n_tokens, float **batch_embeddings) {
+    if (!batch_embeddings) return;   // the reference's memory-probe mode (bert.cpp:739); nothing to size here
+    (void)eval_batch_impl(ctx, n_batch_size, batch_tokens, n_tokens, batch_embeddings);
 }
 
 void bert_eval(struct bert_ctx *ctx, int32_t n_threads, bert_vocab_id *tokens, int32_t n_tokens, float *embeddings) {
@@ -193,15 +200,32 @@ void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batc
                        const char **texts, float **embeddings) {
     if (n_inputs <= 0) return;
     const int32_t N = ctx->hp.n_max_tokens;
-    // tokenize everything (on n_threads host threads: at 10^5 sentences/s on the GPU the tokenizer is the stage in
-    // front of the path that has to keep up), then evaluate as packed device batches (the reference sorts by length
-    // and loops with batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching)
-    std::vector<bert_vocab_id> buf((size_t)N * n_inputs);
-    std::vector<int32_t> n_tokens(n_inputs);
-    std::vector<bert_vocab_id *> ptrs(n_inputs);
-    for (int32_t i = 0; i < n_inputs; ++i) ptrs[i] = buf.data() + (size_t)i * N;
-    tokenize_many(ctx, n_threads, n_inputs, texts, buf.data(), n_tokens.data());
-    bert_eval_batch(ctx, n_threads, n_inputs, ptrs.data(), n_tokens.data(), embeddings);
+    // Tokenize on n_threads host threads (at 10^5 sentences/s on the GPU the tokenizer is the stage in front of the
+    // path that has to keep up) and evaluate as packed device batches (the reference sorts by length and loops with
+    // batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching).  Inputs go through in groups:
+    // group g+1 is tokenized while group g is on the GPU, and the id buffers stay bounded for any n_inputs.
+    constexpr int32_t GROUP = 4096;
+    struct Group {
+        std::vector<bert_vocab_id> ids;
+        std::vector<int32_t> n_tokens;
+        std::vector<bert_vocab_id *> ptrs;
+    } groups[2];
+    auto tokenize_group = [&](Group &g, int32_t i0, int32_t n) {
+        g.ids.resize((size_t)N * n);
+        g.n_tokens.resize(n);
+        g.ptrs.resize(n);
+        for (int32_t i = 0; i < n; ++i) g.ptrs[i] = g.ids.data() + (size_t)i * N;
+        tokenize_many(ctx, n_threads, n, texts + i0, g.ids.data(), g.n_tokens.data());
+    };
+    tokenize_group(groups[0], 0, std::min(GROUP, n_inputs));
+    for (int32_t i0 = 0, k = 0; i0 < n_inputs; i0 += GROUP, ++k) {
+        const int32_t n = std::min(GROUP, n_inputs - i0), n_next = std::min(GROUP, n_inputs - i0 - n);
+        std::thread ahead;
+        if (n_next > 0) ahead = std::thread([&, k, i0, n, n_next] { tokenize_group(groups[(k + 1) & 1], i0 + n, n_next); });
+        const int32_t done = eval_batch_impl(ctx, n, groups[k & 1].ptrs.data(), groups[k & 1].n_tokens.data(), embeddings + i0);
+        if (ahead.joinable()) ahead.join();
+        if (done != n) return;                                // outputs after the failure stay untouched
+    }
 }
 
 int32_t bert_hip_tokenize_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,

@@ -426,6 +426,16 @@ def test_encode_equals_tokenize_plus_eval(make_model, tmp_path):
         assert ids[0] == 101 and ids[-1] == 102
         assert np.array_equal(e, m.eval(ids))
         assert np.array_equal(e, m.encode(t))
+    # more inputs than one group (4096) of bert_encode_batch: group g+1 is tokenized while group g is on the GPU
+    rng = np.random.default_rng(8)
+    pool = ["hello", "world", "testing", "tests", "a", "b", "c", ",", ".", "!", "HELLO", "xyzzy"]
+    many = [" ".join(rng.choice(pool, size=int(rng.integers(0, 12)))) for _ in range(9001)]
+    enc = m.encode_batch(many, n_threads=5)
+    ids = m.tokenize_batch(many, n_threads=3)
+    want = m.eval_batch(ids)
+    assert np.array_equal(enc, want)
+    for i in (0, 4095, 4096, 8191, 8192, 9000):
+        assert np.array_equal(enc[i], m.encode(many[i])), i
 
 
 @pytest.mark.parametrize("dims,ftype", [("tiny-h128", "q4_0"), ("tiny-d64", "q4_1"), ("minilm-l6", "q4_0"), ("tiny", "q4_1")])
