@@ -34,9 +34,14 @@ namespace {
 constexpr int LT_TILE = 16384;
 
 // LT_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no GELU arithmetic, bit 2 no tile barrier,
-// bit 3 no fragment reads, bit 4 no MFMAs — what a component costs is the time its removal saves (tools/variant.sh)
+// bit 3 no fragment reads, bit 4 no MFMAs, bit 5 no GELU filler in the last interval of a chunk, bit 6 no GELU filler at all — what a component costs is the time its removal saves (tools/variant.sh)
 #ifndef LT_ABLATE
 #define LT_ABLATE 0
+#endif
+// LT_GROLE: -1 = the two GELU'ed-chunk buffers alternate roles with the chunk parity; 0 / 1 = the down-projection always
+// reads g[LT_GROLE], the filler always writes the other one, which is copied over once per chunk
+#ifndef LT_GROLE
+#define LT_GROLE 1
 #endif
 struct TailArgs {
     const half_t *ctx, *x;            // [T_pad][H]
@@ -465,26 +470,39 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     drain(TileDesc<K_UP, 0, NT - 1>{});
     static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
         static_for<4>([&](auto p_tag) __attribute__((always_inline)) {
-            gelu_pair(H0{}, j_tag, p_tag, *(const f32x2 *)(cb1 + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
+            gelu_pair(std::integral_constant<int, (LT_GROLE < 0 ? 0 : (LT_GROLE ^ 1))>{}, j_tag, p_tag, *(const f32x2 *)(cb1 + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
         });
     });
 
     // ---- step c: UP(c+1), then DOWN(c) with gelu(c+1) as filler.  GP = c & 1 (g buffer of chunk c).
     // FIRST: c == 0; LAST: c == NC - 2 (no UP(c+2) to request: a separate instantiation keeps the requests branch-free)
     auto step = [&](auto gp_tag, auto first_tag, auto last_tag, int c) __attribute__((always_inline)) {
-        constexpr int GP = decltype(gp_tag)::value;
+        constexpr int GPT = decltype(gp_tag)::value;
+        constexpr int GP = LT_GROLE < 0 ? GPT : LT_GROLE;          // buffer DOWN(c) reads
+        constexpr int GW = GP ^ 1;                                  // buffer gelu(c+1) is written to
+        constexpr int GE = LT_GROLE < 0 ? GP ^ 1 : GP;              // buffer the tile owed on entry (of DOWN(c-1)) reads
         constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        // fixed roles: chunk c, written to g[GW] during the previous step, moves to g[GP] behind the last owed MFMA
+        auto move_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[GP][j] = g[GW][j];
+        };
+        if constexpr (LT_GROLE >= 0 && FIRST) move_chunk();
+        auto after_owed = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
+            if constexpr (LT_GROLE >= 0 && decltype(grp_tag)::value == 0 && decltype(k_tag)::value == 7) move_chunk();
+        };
         static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
             constexpr int j = decltype(j_tag)::value;
             using Cur = TileDesc<K_UP, 0, j>;
             // owed on entry: nothing after the exposed gelu(0), else the last tile of DOWN(c-1)
-            using Entry = std::conditional_t<FIRST, NoTile, TileDesc<K_DOWN, GP ^ 1, NT - 1>>;
+            using Entry = std::conditional_t<FIRST, NoTile, TileDesc<K_DOWN, GE, NT - 1>>;
             using Prev = std::conditional_t<j == 0, Entry, TileDesc<K_UP, 0, j - 1>>;
             auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
                 constexpr int j2 = j + 2;
                 if constexpr (j2 < NT) dma_up(c + 1, j2, s2, pc); else dma_down(c, j2 - NT, s2, pc);
             };
-            interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
+            if constexpr (j == 0 && !FIRST) interval(Cur{}, Prev{}, VM4{}, pf, after_owed, nothing1, nothing1);
+            else interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
         });
         static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
             constexpr int d = decltype(d_tag)::value;
@@ -513,8 +531,8 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             };
             auto fill = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
                 constexpr int grp = decltype(grp_tag)::value, k = decltype(k_tag)::value, q = lt_pair_of<NT>(d, grp * 8 + k);
-                if constexpr (q >= 0)
-                    gelu_pair(std::integral_constant<int, GP ^ 1>{}, std::integral_constant<int, q / 4>{},
+                if constexpr (q >= 0 && !((LT_ABLATE & 32) && q >= 10) && !(LT_ABLATE & 64))
+                    gelu_pair(std::integral_constant<int, GW>{}, std::integral_constant<int, q / 4>{},
                               std::integral_constant<int, q % 4>{}, Bv[grp][lt_pair_rank<NT>(d, grp, k)]);
             };
             interval(Cur{}, Prev{}, VM4{}, pf, fill, pre, fence);
@@ -522,25 +540,38 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     };
     // NC is even and >= 4: steps c = 0 .. NC-2 (GP = c & 1), the last one with GP = 0
     step(H0{}, std::true_type{}, std::false_type{}, 0);
+#if LT_GROLE >= 0
+    // fixed roles: one copy of the step in the loop
+    for (int c = 1; c + 2 < NC; ++c) step(H1{}, std::false_type{}, std::false_type{}, c);
+#else
     for (int c = 1; c + 3 < NC; c += 2) {
         step(H1{}, std::false_type{}, std::false_type{}, c);
         step(H0{}, std::false_type{}, std::false_type{}, c + 1);
     }
     step(H1{}, std::false_type{}, std::false_type{}, NC - 3);
+#endif
     step(H0{}, std::false_type{}, std::true_type{}, NC - 2);
     // ---- DOWN(NC-1)
     auto last_down = [&](auto gp_tag) __attribute__((always_inline)) {
-        constexpr int GP = decltype(gp_tag)::value;
+        constexpr int GP = LT_GROLE < 0 ? decltype(gp_tag)::value : LT_GROLE;
+        constexpr int GE = LT_GROLE < 0 ? GP ^ 1 : GP;
+        auto after_owed = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
+            if constexpr (LT_GROLE >= 0 && decltype(grp_tag)::value == 0 && decltype(k_tag)::value == 7) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[GP][j] = g[GP ^ 1][j];
+            }
+        };
         static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
             constexpr int d = decltype(d_tag)::value;
             using Cur = TileDesc<K_DOWN, GP, d>;
-            using Prev = std::conditional_t<d == 0, TileDesc<K_DOWN, GP ^ 1, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
+            using Prev = std::conditional_t<d == 0, TileDesc<K_DOWN, GE, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
             auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
                 constexpr int d2 = d + 2;
                 if constexpr (d2 < NT) dma_down(NC - 1, d2, s2, pc);
             };
             constexpr int vm = d + 2 < NT ? 4 : 0;
-            interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing, nothing1, nothing1);
+            if constexpr (d == 0) interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, after_owed, nothing1, nothing1);
+            else interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing, nothing1, nothing1);
         });
         drain(TileDesc<K_DOWN, GP, NT - 1>{});
     };
