@@ -56,8 +56,15 @@ public:
     int eval_packed_host(const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, float *embeddings,
                          std::string &err);
     // device-resident, asynchronous on `stream`
+    // d_windows / n_windows: optional sentence windows of the fused projection+attention kernel (build_windows), in
+    // device memory; without them sentences are placed by the uniform rule of qkv_attention2.hip
     int eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int n_sentences, int n_tokens, int max_len,
-                           float *d_out, hipStream_t stream, float *d_hidden, std::string &err);
+                           float *d_out, hipStream_t stream, float *d_hidden, std::string &err,
+                           const int2 *d_windows = nullptr, int n_windows = 0);
+    // next-fit packing of whole sentences (in order, each starting at a multiple of 16 slots) into windows of 128 token
+    // slots: {first sentence, count} per window.  Sentences longer than a window get one of their own (the fused kernel is
+    // not used for such batches).
+    static void build_windows(const int32_t *cu_seqlens, int n_sentences, std::vector<int2> &windows);
     int eval_hidden(const int32_t *tokens, int n_tokens, float *hidden, float *embedding, std::string &err);
 
     void set_option(const std::string &key, const std::string &value);
@@ -87,12 +94,14 @@ private:
         int32_t *h_tokens = nullptr, *h_cu = nullptr;
         float *h_out = nullptr;
         size_t h_tokens_cap = 0, h_cu_cap = 0, h_out_cap = 0;
-        DevBuf d_tokens, d_cu, d_out;
+        DevBuf d_tokens, d_cu, d_out, d_windows;
+        int2 *h_windows = nullptr;
+        size_t h_windows_cap = 0;
         hipEvent_t done = nullptr;
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, tail_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, qkv2_ = true, tail_ = true, q4_expand_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

@@ -191,6 +191,7 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
     if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_QKV2")) e->qkv2_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
@@ -241,6 +242,7 @@ Engine::~Engine() {
         if (sl.h_tokens) (void)hipHostFree(sl.h_tokens);
         if (sl.h_cu) (void)hipHostFree(sl.h_cu);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_windows) (void)hipHostFree(sl.h_windows);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -254,6 +256,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "panel") panel_ = value != "0";
     else if (key == "layer_fused") layer_fused_ = value != "0";
     else if (key == "qkv_att") qkv_att_ = value != "0";
+    else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
@@ -305,8 +308,22 @@ std::string Engine::profile_report() {
     return out;
 }
 
+void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows) {
+    windows.clear();
+    int first = 0, fill = 0;                                  // open window: sentences first .. b-1 occupy `fill` slots
+    for (int b = 0; b < B; ++b) {
+        const int n = cu[b + 1] - cu[b];
+        if (b > first && fill + n > 128) {
+            windows.push_back(make_int2(first, b - first));
+            first = b; fill = 0;
+        }
+        fill = (fill + n + 15) & ~15;
+    }
+    if (B > first) windows.push_back(make_int2(first, B - first));
+}
+
 int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int B, int T, int max_len, float *d_out,
-                               hipStream_t s, float *d_hidden, std::string &err) {
+                               hipStream_t s, float *d_hidden, std::string &err, const int2 *d_windows, int n_windows) {
     if (B <= 0 || T <= 0) return 0;
     HIP_OK(hipSetDevice(device_), err, -1);
     const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
@@ -336,6 +353,12 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const double att_flops = 4.0 * Td * max_len * H;
     for (int il = 0; il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
+        if (qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
+            // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths
+            timed("qkv_attention2", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
+                launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, max_len, nh, ctx, s);
+            });
+        } else
         // one workgroup per sentence pays for 128 tokens whatever the length: worth it from ~48 tokens on average
         if (qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && (long long)T >= 48ll * B &&
             qkv_attention_supported(L.qkv.w, nh, dh, max_len)) {
@@ -429,7 +452,9 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         if (!ensure_pinned((void **)&sl.h_tokens, &sl.h_tokens_cap, max_T * 4, err)) return -1;
         if (!ensure_pinned((void **)&sl.h_cu, &sl.h_cu_cap, (max_nb + 1) * 4, err)) return -1;
         if (!ensure_pinned((void **)&sl.h_out, &sl.h_out_cap, max_nb * H * 4, err)) return -1;
-        if (!sl.d_tokens.ensure(max_T * 4, err) || !sl.d_cu.ensure((max_nb + 1) * 4, err) || !sl.d_out.ensure(max_nb * H * 4, err)) return -1;
+        if (!ensure_pinned((void **)&sl.h_windows, &sl.h_windows_cap, max_nb * sizeof(int2), err)) return -1;
+        if (!sl.d_tokens.ensure(max_T * 4, err) || !sl.d_cu.ensure((max_nb + 1) * 4, err) || !sl.d_out.ensure(max_nb * H * 4, err) ||
+            !sl.d_windows.ensure(max_nb * sizeof(int2), err)) return -1;
         if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
     }
     if (!ensure_workspace((int)((max_T + GEMM_BM - 1) / GEMM_BM * GEMM_BM), (int)max_nb, err)) return -1;
@@ -443,18 +468,26 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         return true;
     };
     auto fail = [&]() { (void)hipStreamSynchronize(stream_); return -1; };        // nothing may stay queued on the slots
+    std::vector<int2> windows;
     for (size_t i = 0; i < chunks.size(); ++i) {
         HostSlot &sl = slot_[i & 1];
         const int b0 = chunks[i].b0, nb = chunks[i].b1 - b0, T = cu[chunks[i].b1] - cu[b0];
         memcpy(sl.h_tokens, tokens + cu[b0], (size_t)T * 4);
         for (int j = 0; j <= nb; ++j) sl.h_cu[j] = cu[b0 + j] - cu[b0];
+        int n_windows = 0;
+        if (chunks[i].max_len <= 128) {
+            build_windows(sl.h_cu, nb, windows);
+            n_windows = (int)windows.size();
+            memcpy(sl.h_windows, windows.data(), windows.size() * sizeof(int2));
+        }
         if (hipMemcpyAsync(sl.d_tokens.p, sl.h_tokens, (size_t)T * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
-            hipMemcpyAsync(sl.d_cu.p, sl.h_cu, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess) {
+            hipMemcpyAsync(sl.d_cu.p, sl.h_cu, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
+            (n_windows && hipMemcpyAsync(sl.d_windows.p, sl.h_windows, (size_t)n_windows * sizeof(int2), hipMemcpyHostToDevice, stream_) != hipSuccess)) {
             err = "hipMemcpyAsync (ids) failed";
             return fail();
         }
         if (eval_packed_device(sl.d_tokens.as<int32_t>(), sl.d_cu.as<int32_t>(), nb, T, chunks[i].max_len, sl.d_out.as<float>(),
-                               stream_, nullptr, err) != 0)
+                               stream_, nullptr, err, n_windows ? sl.d_windows.as<int2>() : nullptr, n_windows) != 0)
             return fail();
         if (hipMemcpyAsync(sl.h_out, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
             hipEventRecord(sl.done, stream_) != hipSuccess) {

@@ -84,6 +84,16 @@ bool qkv_attention_supported(const GemmWeight &Wqkv, int n_head, int d_head, int
 void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
                           int n_sentences, int n_head, half_t *out, hipStream_t stream);
 
+// Second generation (qkv_attention2.hip): a workgroup owns a window of 128 token slots holding one or several whole
+// sentences (16-slot aligned); f16 weights, d_head 32, H = 128 / 256 / 384, every sentence <= 128 tokens.
+// `groups` [n_groups] = {first sentence, count} per window (device memory), or nullptr: the uniform rule
+// 128 / round_up(max_len, 16) sentences per window.
+bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);
+int qkv_attention2_sentences_per_window(int max_len);
+void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
+                           int n_sentences, const int2 *groups, int n_groups, int max_len, int n_head, half_t *out,
+                           hipStream_t stream);
+
 // mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
                            hipStream_t stream);

@@ -43,6 +43,29 @@ constexpr int LT_TILE = 16384;
 #ifndef LT_GROLE
 #define LT_GROLE 1
 #endif
+// LT_GELU16: the GELU of the intermediate is evaluated in packed f16 (two elements per instruction where the ISA has a
+// packed form; the reference reads it from an f16 table, ggml_gelu_f16), 0 = f32 arithmetic per element
+#ifndef LT_GELU16
+#define LT_GELU16 1
+#endif
+// LT_BIASINIT: the up-projection accumulators start from the bias of their chunk (written where they used to be
+// zeroed) instead of the bias being added in front of the GELU
+#ifndef LT_BIASINIT
+#define LT_BIASINIT 1
+#endif
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// tanh-form GELU of two values, packed f16: x / (1 + 2^(x (c1 + c2 x^2)))
+__device__ __forceinline__ f16x2_t gelu_pk16(float a0, float a1) {
+    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
+    const f16x2_t C1 = {(_Float16)c1, (_Float16)c1}, C2 = {(_Float16)(c1 * 0.044715f), (_Float16)(c1 * 0.044715f)};
+    const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+    const f16x2_t xh = {(_Float16)a0, (_Float16)a1};
+    const f16x2_t t = (xh * xh * C2 + C1) * xh;
+    const f16x2_t e = {(_Float16)__builtin_exp2f16(t[0]), (_Float16)__builtin_exp2f16(t[1])};
+    const f16x2_t d = e + one;
+    const f16x2_t r = {(_Float16)__builtin_amdgcn_rcph(d[0]), (_Float16)__builtin_amdgcn_rcph(d[1])};
+    return xh * r;
+}
 struct TailArgs {
     const half_t *ctx, *x;            // [T_pad][H]
     const half_t *wo;                 // [H_pad][H] f16
@@ -348,13 +371,20 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     auto gelu_pair = [&](auto par_tag, auto j_tag, auto p_tag, f32x2 b) __attribute__((always_inline)) {
         constexpr int par = decltype(par_tag)::value, j = decltype(j_tag)::value, fb = j >> 1, s = j & 1;
         constexpr int p = decltype(p_tag)::value;             // elements 2p, 2p+1 of the fragment = registers 8s + 2p, +1
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            constexpr int e0 = 2 * p;
-            const float xv = accU[fb][8 * s + e0 + t] + b[t];
-            g[par][j][e0 + t] = (LT_ABLATE & 2) ? (_Float16)xv : (_Float16)gelu_fast(xv);
-            accU[fb][8 * s + e0 + t] = 0.f;
+        constexpr int e0 = 2 * p;
+        // b = the biases of THIS chunk (added here) or, with LT_BIASINIT, of the chunk the accumulators serve next
+        const float x0 = LT_BIASINIT ? accU[fb][8 * s + e0] : accU[fb][8 * s + e0] + b[0];
+        const float x1 = LT_BIASINIT ? accU[fb][8 * s + e0 + 1] : accU[fb][8 * s + e0 + 1] + b[1];
+        if constexpr (LT_ABLATE & 2) {
+            g[par][j][e0] = (_Float16)x0; g[par][j][e0 + 1] = (_Float16)x1;
+        } else if constexpr (LT_GELU16) {
+            const f16x2_t gv = gelu_pk16(x0, x1);
+            g[par][j][e0] = gv[0]; g[par][j][e0 + 1] = gv[1];
+        } else {
+            g[par][j][e0] = (_Float16)gelu_fast(x0); g[par][j][e0 + 1] = (_Float16)gelu_fast(x1);
         }
+        accU[fb][8 * s + e0] = LT_BIASINIT ? b[0] : 0.f;
+        accU[fb][8 * s + e0 + 1] = LT_BIASINIT ? b[1] : 0.f;
     };
     // bias of pair (j, p) of a chunk: features 32fb + 16s + 4hi + {2p, 2p+1} (p < 2) or + 8 + {2p-4, 2p-3}, as a float offset
     // into the chunk's 64 biases without the 4hi part
@@ -447,7 +477,8 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int fb = 0; fb < 2; ++fb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accU[fb][r] = 0.f;
+        for (int r = 0; r < 16; ++r)          // register r of block fb = feature 32 fb + (r & 3) + 8 (r >> 2) + 4 hi of the chunk
+            accU[fb][r] = LT_BIASINIT ? cb1[32 * fb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
@@ -470,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
     drain(TileDesc<K_UP, 0, NT - 1>{});
     static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
         static_for<4>([&](auto p_tag) __attribute__((always_inline)) {
-            gelu_pair(std::integral_constant<int, (LT_GROLE < 0 ? 0 : (LT_GROLE ^ 1))>{}, j_tag, p_tag, *(const f32x2 *)(cb1 + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
+            gelu_pair(std::integral_constant<int, (LT_GROLE < 0 ? 0 : (LT_GROLE ^ 1))>{}, j_tag, p_tag, *(const f32x2 *)(cb1 + (LT_BIASINIT ? 64 : 0) + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
         });
     });
 
@@ -517,7 +548,7 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             // the 16 element pairs of gelu(c+1) behind the MFMAs of the NT intervals (lt_pair_of); their biases are read
             // by hand one group of 8 MFMA slots ahead
             f32x2 Bv[2][6];
-            const unsigned aBc = aB + (unsigned)(c + 1) * 256u;
+            const unsigned aBc = aB + (unsigned)(c + 1 + LT_BIASINIT) * 256u;      // (LT_BIASINIT: one chunk past the end in the last step, never used)
             auto pre = [&](auto grp_tag) __attribute__((always_inline)) {
                 constexpr int grp = decltype(grp_tag)::value;
                 static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
@@ -653,7 +684,7 @@ bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gemm
     if (Wo.type != GW_F16 || W1.type != GW_F16 || W2.type != GW_F16 || !W1.w16p || !W2.w16p) return false;
     if (Wo.N != H || Wo.K != H || W2.N != H || W2.K != I) return false;
     if (H % 128 != 0 || H < 256 || H > 384 || I % 128 != 0 || I < 256) return false;     // an even number >= 4 of 64-feature chunks
-    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + I) * sizeof(float);
+    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + I + 64) * sizeof(float);
     return lds <= 160 * 1024;
 }
 
@@ -664,7 +695,7 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
     a.ctx = ctx; a.x = x; a.wo = Wo.w16; a.w1p = W1.w16p; a.w2p = W2.w16p;
     a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out; a.I = W1.N;
     const int H = W1.K, NT = H / 128;
-    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + a.I) * sizeof(float);
+    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + a.I + 64) * sizeof(float);
     static bool configured[4] = {};
     auto go = [&](auto kernel) __attribute__((always_inline)) {
         if (!configured[NT]) {

@@ -195,7 +195,20 @@ int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqle
         return -1;
     }
     CK(hipMemcpy(dx.p, x, (size_t)T * H * 2, hipMemcpyHostToDevice));
-    if (fused) {
+    if (fused == 2 || fused == 3) {
+        // second-generation kernel: 2 = next-fit windows of whole sentences, 3 = the uniform placement rule
+        if (!qkv_attention2_supported(ws.w, n_head, d_head, max_len)) return -2;
+        std::vector<int2> win;
+        DevBuf dwin;
+        if (fused == 2) {
+            Engine::build_windows(cu_seqlens, n_sentences, win);
+            if (!dwin.upload(win.data(), win.size() * sizeof(int2), err)) return -1;
+        }
+        launch_qkv_attention2(ws.w, dx.as<half_t>(), db.as<float>(), dcu.as<int32_t>(), n_sentences,
+                              fused == 2 ? dwin.as<int2>() : nullptr, (int)win.size(), max_len, n_head, dout.as<half_t>(), nullptr);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+    } else if (fused) {
         if (!qkv_attention_supported(ws.w, n_head, d_head, max_len)) return -2;
         launch_qkv_attention(ws.w, dx.as<half_t>(), db.as<float>(), dcu.as<int32_t>(), n_sentences, n_head, dout.as<half_t>(), nullptr);
     } else {

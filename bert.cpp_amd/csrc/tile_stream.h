@@ -50,7 +50,23 @@ static __device__ unsigned long long g_timeline[1024 * 256];
         }                                                                                                     \
     }                                                                                                         \
 } while (0)
+// raw stamps relative to stamp 0 (kernels whose waves stamp disjoint index ranges)
+#define TL_DUMP_RAW(cond, nstamps) do {                                                                      \
+    static int tl_shots = 0;                                                                                  \
+    if ((cond) && tl_shots++ == 20) {                                                                         \
+        (void)hipDeviceSynchronize();                                                                         \
+        static unsigned long long tl_h[1024 * 256];                                                           \
+        (void)hipMemcpyFromSymbol(tl_h, HIP_SYMBOL(g_timeline), sizeof(tl_h));                                \
+        for (int b : {0, 100}) {                                                                              \
+            fprintf(stderr, "rawtimeline wg %3d:", b);                                                        \
+            for (int i = 0; i < (nstamps); ++i)                                                               \
+                fprintf(stderr, " %lld", tl_h[b * 256 + i] ? (long long)(tl_h[b * 256 + i] - tl_h[b * 256]) : -1LL); \
+            fprintf(stderr, "\n");                                                                            \
+        }                                                                                                     \
+    }                                                                                                         \
+} while (0)
 #else
+#define TL_DUMP_RAW(cond, nstamps) do { } while (0)
 #define TL_STAMP(i) do { } while (0)
 #define TL_STAMP_AT(sel, i) do { } while (0)
 #define TL_DUMP(cond, nstamps) do { } while (0)

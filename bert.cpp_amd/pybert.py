@@ -259,7 +259,7 @@ def test_qkv_attention(x: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_hea
     bias = np.ascontiguousarray(bias, dtype=np.float32)
     out = np.zeros((x.shape[0], n_head * d_head), dtype=np.float16)
     r = L.bert_hip_test_qkv_attention(len(cu) - 1, _i32p(cu), n_head, d_head, x.ctypes.data, w.ctypes.data, wtype,
-                                      bias.ctypes.data, 1 if fused else 0, out.ctypes.data)
+                                      bias.ctypes.data, int(fused), out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_qkv_attention failed: {r}")
     return out

@@ -246,6 +246,64 @@ def test_qkv_attention_fused_kernel_q4(n_head, lens, wtype):
     assert err.max() < 1e-2, (n_head, lens, float(err.max()))
 
 
+Q2_CASES = [
+    [128, 128, 128],
+    [1, 2, 5, 31, 32, 33, 64, 100, 127, 128],
+    [96, 97, 48],
+    list(range(1, 48)),                       # short sentences: several per 128-slot window
+    [16, 16, 16, 16, 16, 16, 16, 16, 15, 17, 1, 1, 1, 1, 1, 1, 1, 1, 1, 112],
+    [40, 3, 77, 128, 9, 9, 64, 64, 63, 65, 20],
+]
+
+
+@pytest.mark.parametrize("mode", [2, 3], ids=["next-fit", "uniform"])
+@pytest.mark.parametrize("n_head", [4, 8, 12])
+@pytest.mark.parametrize("lens", Q2_CASES, ids=[f"case{i}" for i in range(len(Q2_CASES))])
+def test_qkv_attention2_kernel(n_head, lens, mode):
+    """Second-generation fused projection + attention (qkv_attention2.hip: windows of 128 token slots holding whole
+    sentences, projection waves own token blocks): equal bits with the two-kernel path whatever window a sentence lands
+    in, and within f16 rounding of a float64 reference of reference bert.cpp:822-856."""
+    d_head, H = 32, 32 * n_head
+    rng = np.random.default_rng(sum(lens) + n_head)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    T = int(cu[-1])
+    x = rng.normal(0, 1, (T, H)).astype(np.float16)
+    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float16)
+    W[:H] *= 1.7
+    W[:, : H // 2] *= 1.3                      # asymmetric in k: a permuted k-tile cannot pass
+    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
+    got = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, mode)
+    split = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, 0)
+    qkv = (x.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float16)
+    want = _attention_ref(qkv, cu, n_head, d_head)
+    err = np.abs(got.astype(np.float64) - want)
+    bad = np.argwhere(err > 6e-3)
+    assert err.max() < 6e-3, (n_head, mode, float(err.max()), bad[:8].tolist(), len(bad))
+    neq = np.argwhere(got.view(np.uint16) != split.view(np.uint16))
+    assert len(neq) == 0, (n_head, mode, len(neq), neq[:8].tolist())
+
+
+def test_qkv_attention2_same_bits_in_any_window():
+    """A sentence gives the same bits alone in a window, behind other sentences, or at another 16-slot offset."""
+    n_head, d_head, H = 12, 32, 384
+    rng = np.random.default_rng(77)
+    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float16)
+    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
+    sents = [rng.normal(0, 1, (n, H)).astype(np.float16) for n in (23, 40, 7, 16, 33)]
+
+    def run(order):
+        xs = np.concatenate([sents[i] for i in order])
+        cu = np.concatenate([[0], np.cumsum([len(sents[i]) for i in order])]).astype(np.int32)
+        out = pybert.test_qkv_attention(xs, cu, n_head, d_head, W.view(np.uint8), 1, bias, 2)
+        return {i: out[cu[k]:cu[k + 1]] for k, i in enumerate(order)}
+
+    alone = {i: run([i])[i] for i in range(len(sents))}
+    for order in ([0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [2, 0, 4, 1, 3]):
+        got = run(order)
+        for i in order:
+            assert np.array_equal(got[i].view(np.uint16), alone[i].view(np.uint16)), (order, i)
+
+
 def test_qkv_attention_fused_kernel_limits():
     rng = np.random.default_rng(0)
     H = 128
