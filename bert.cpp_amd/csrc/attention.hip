@@ -121,19 +121,21 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = key < n ? s[kt][r] * sc : -INFINITY;
+                    const float v = key < n ? s[kt][r] : -INFINITY;
                     s[kt][r] = v;
                     mx = fmaxf(mx, v);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);           // finite: every chunk has >= 1 real key
+            // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit; the exponent below is one
+            // fma per score (the same arithmetic as qkv_attention.hip / qkv_attention2.hip: equal bits across the kernels)
+            const float m_new = fmaxf(m_run, mx * sc);      // finite: every chunk has >= 1 real key
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
             float psum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
                     s[kt][r] = pv;
                     psum += pv;
                 }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
                 for (int g = 0; g < 4; ++g) {
                     f16x4 ov;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(o[dv][4 * g + e] * inv);
+                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)rounded_f32(o[dv][4 * g + e] * inv);
                     *(f16x4 *)(op + dv * 32 + 8 * g + 4 * hi) = ov;
                 }
         }

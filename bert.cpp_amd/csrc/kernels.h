@@ -11,6 +11,15 @@ namespace bert_hip {
 
 typedef _Float16 half_t;
 
+// An f32 value the compiler must materialise: (_Float16)rounded_f32(a * b) is an f32 multiply followed by a conversion,
+// never the fused v_fma_mixlo_f16 (ONE rounding, to f16).  Which of the two forms the compiler picks for (_Float16)(a * b)
+// depends on the surrounding code, and kernels that must agree bit for bit (attention.hip, qkv_attention*.hip) would
+// differ in one result of ~20 000.
+__device__ __forceinline__ float rounded_f32(float v) {
+    asm("" : "+v"(v));
+    return v;
+}
+
 constexpr int GEMM_BM = 128;   // token tile
 constexpr int GEMM_BN = 128;   // feature tile
 constexpr int GEMM_BK = 64;    // reduction tile (two 32-weight quant blocks)

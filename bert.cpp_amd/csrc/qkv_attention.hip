@@ -361,17 +361,17 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const float v = key < n ? s[kt][r] * sc : -INFINITY;
+                        const float v = key < n ? s[kt][r] : -INFINITY;
                         s[kt][r] = v;
                         mx = fmaxf(mx, v);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;      // = the maximum of the scaled scores (sc > 0), as attention.hip
                 float psum = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -mx));
                         s[kt][r] = pv;
                         psum += pv;
                     }
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention_kernel(QkvAttArgs a) {
                     for (int gq = 0; gq < 4; ++gq) {
                         f16x4 ov;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(o[4 * gq + e] * inv);
+                        for (int e = 0; e < 4; ++e) ov[e] = (_Float16)rounded_f32(o[4 * gq + e] * inv);
                         *(f16x4 *)(op + 8 * gq + 4 * hi) = ov;
                     }
                 }

@@ -13,8 +13,10 @@
 //   waves 0..3  "attention" waves: wave a owns query block a of the head projected one step earlier: S^T = K Q^T,
 //               softmax over the keys of the query's own sentence, O^T = V^T P^T, normalise, store (as attention.hip).
 // Wave a and wave a+4 share a SIMD: the projection MFMAs run under the softmax VALU work, and every SIMD carries the
-// same number of MFMAs (72 + 16 per head).  Per head the two groups meet at NBAR+1 barriers: the slab barriers (the
-// last one doubles as "attention is done with the previous head's Q/K/V^T") and "Q/K/V^T of this head are published".
+// same number of MFMAs (72 + 16 per head).  Q_h / K_h / V_h^T are double-buffered in LDS (head h in buffer h & 1), so
+// the projection waves never wait for the attention of the previous head; per head the two groups meet at NBAR+1
+// barriers — the slab barriers and "Q/K/V^T of this head are published" — which the attention waves execute at
+// matching points of their own work (Q2_P1 / Q2_P2) so that neither group waits long for the other.
 //
 // Windows and bit-exactness: sentence j of the window starts at slot off_j with off_0 = 0, off_{j+1} = off_j + n_j
 // rounded up to 16.  A softmax row only ever sees the keys of its own sentence (the others are masked with -inf before
@@ -24,6 +26,18 @@
 // that no query of a block needs are skipped, tiles that lie inside the sentence of every query of the block are not
 // masked at all.
 #include "tile_stream.h"
+
+// tuning knobs (A/B builds): the attention waves execute the head's first barrier after S-step Q2_P1 and the second after
+// PV-step Q2_P2 (steps 0..3 = key tiles); Q2_PRIO = s_setprio level of the attention waves
+#ifndef Q2_P1
+#define Q2_P1 2
+#endif
+#ifndef Q2_P2
+#define Q2_P2 1
+#endif
+#ifndef Q2_PRIO
+#define Q2_PRIO 0
+#endif
 
 namespace bert_hip {
 
@@ -64,6 +78,24 @@ __device__ __forceinline__ void q2_slab_barrier(f16x8 (&f)[2][3]) {
     asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
                  : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]) : "n"(VM) : "memory");
 }
+// the same wait, also handing over the eight hand-read bias vectors (older than the six reads left in flight)
+__device__ __forceinline__ void q2_wait6_bias(f16x8 (&f)[2][3], f32x4 (&bq)[4], f32x4 (&bk)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(6)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]),
+                   "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bk[0]), "+v"(bk[1]), "+v"(bk[2]), "+v"(bk[3]) : : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ f32x4 q2_read_f32x4(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+// last slab barrier of a head: also hands over the V bias (a global load older than every DMA piece that may stay in flight)
+template <int VM>
+__device__ __forceinline__ void q2_slab_barrier_bias(f16x8 (&f)[2][3], float &bv) {
+    asm volatile("s_waitcnt vmcnt(%7) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]), "+v"(bv) : "n"(VM) : "memory");
+}
 __device__ __forceinline__ void q2_publish_barrier(f16x8 (&f)[2][3]) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier"
                  : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]) : : "memory");
@@ -77,11 +109,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 64 * KT, NBAR = KT / GB, SLAB = GB * Q2_TILE, PPS = 3 * GB;   // PPS = DMA pieces per slab and wave
     static_assert(KT % GB == 0 && NBAR >= 1 && NBAR <= 2, "");
+    constexpr int QKV_BYTES = 2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2;   // Q [128][32] + K [128][32] (q2_off32 swizzle) + V^T [32][Q2_VT_LD]
     char *RING = smem;                                        // 3 slabs
-    char *QS = smem + 3 * SLAB;                               // [128][32] halfs, q2_off32 swizzle
-    char *KS = QS + Q2_WIN * 64;
-    half_t *VT = (half_t *)(KS + Q2_WIN * 64);                // [32][Q2_VT_LD]
-    float *BS = (float *)((char *)VT + 32 * Q2_VT_LD * 2);    // [3H] bias
+    char *QKV = smem + 3 * SLAB;                              // two copies: head h in copy h & 1
+    float *BS = (float *)(QKV + 2 * QKV_BYTES);               // [2H] Q and K bias (the V bias comes from global memory)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             off = (off + n + 15) & ~15;
         }
     }
-    for (int i = tid; i < 3 * H; i += 512) BS[i] = a.bias[i];
+    for (int i = tid; i < 2 * H; i += 512) BS[i] = a.bias[i];
 
     if (wave >= 4) {
         // =============================== projection wave: token block `blk` ===============================
@@ -120,20 +151,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         }
         // DMA: piece (i) of a slab for this wave = tile i / 3, row block rb = i % 3 (Q, K, V rows), rows wp*8 .. +8 of it
         const unsigned loff = (unsigned)(((wp * 8 + (lane >> 3)) * H + (((lane & 7) ^ (((wp & 1) << 2) | ((lane >> 4) & 3))) * 8)) * 2);
-        const int S = n_head * NBAR;                          // slabs in total
-        auto dma_piece = [&](int sl, int dslot, auto i_tag) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_tag)::value, t = i / 3, rb = i % 3;
-            const int h = sl / NBAR, j = sl - h * NBAR;
-            const char *src = (const char *)a.w + ((size_t)(rb * H + h * 32) * H + (size_t)(j * GB + t) * 64) * 2;
+        // piece i of slab j (compile time) of the head whose Q rows start at `hbase`
+        auto dma_piece = [&](const char *hbase, auto j_tag, int dslot, auto i_tag) __attribute__((always_inline)) {
+            constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value, t = i / 3, rb = i % 3;
+            const char *src = hbase + ((size_t)rb * H * H + (size_t)(j * GB + t) * 64) * 2;
             __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + loff), AS_LDS(RING + dslot * SLAB + t * Q2_TILE + rb * 4096 + wp * 1024), 16, 0, 0);
         };
-        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(0, 0, i); });
-        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(S > 1 ? 1 : 0, 1, i); });
-
+        const char *const wbase = (const char *)a.w;
+        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, 0>{}, 0, i); });
+        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, NBAR - 1>{}, 1, i); });
         // per-lane LDS address of the weight fragment of k-step kk of a tile: the chunk swizzle is an XOR of 2*kk + hi
         const unsigned aX0 = lds_addr(RING) + off64(l31, hi);
         unsigned aS[4];
-        int rslot = 0, sl = 0;                                // ring slot and index of the slab being multiplied
+        int rslot = 0;                                        // ring slot of the slab being multiplied
         auto set_slot = [&]() __attribute__((always_inline)) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) aS[kk] = (aX0 ^ (unsigned)(kk << 5)) + (unsigned)rslot * SLAB;
@@ -157,7 +187,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         TL_STAMP_AT(tl_sel, 1);
         read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
+        const unsigned aBias = lds_addr(BS) + 16 * hi;          // Q bias of features 8 gg + 4 hi .. of head h at + (h * 32 + 8 gg) * 4
         for (int h = 0; h < n_head; ++h) {
+            char *QS = QKV + (h & 1) * QKV_BYTES, *KS = QS + Q2_WIN * 64;
+            half_t *VT = (half_t *)(KS + Q2_WIN * 64);
+            // V bias of this lane's feature: an untracked global load, older than every DMA piece requested during the
+            // head, so the counted waits of the slab barriers cover it
+            float bv;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(a.bias + 2 * H + h * 32 + l31));
+            f32x4 bq[4], bk[4];
+            // slab j of this head requests slab j of the next head (two slabs ahead); past the end the last head's
+            // slabs are requested again, into slots nobody reads any more
+            const char *const hnext = wbase + (size_t)min(h + 1, n_head - 1) * 32 * H * 2;
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -169,47 +210,58 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                 constexpr int hs = hh % (2 * GB);                                  // half index inside the slab
                 // the pieces of slab sl+2 go behind the MFMAs of slab sl (piece i in half (2 i) / 3 of the slab), into the
                 // slot slab sl-1 was read from.  (Taken before the crossing update: this half still belongs to slab sl.)
-                const int sreq = min(sl + 2, S - 1), dslot = rslot == 0 ? 2 : rslot - 1;
+                const int dslot = rslot == 0 ? 2 : rslot - 1;
                 if constexpr (crossing) {
                     if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + (hh == 2 * KT - 1 ? 2 : 0));
                     // outstanding here, oldest first: the next slab (complete), then the slab after it WITHOUT the one
                     // piece this last half is about to request
-                    q2_slab_barrier<PPS - 1>(F[par]);
+                    if constexpr (hh == 2 * KT - 1) q2_slab_barrier_bias<PPS - 1>(F[par], bv);
+                    else q2_slab_barrier<PPS - 1>(F[par]);
                     if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + (hh == 2 * KT - 1 ? 3 : 1));
                     rslot = rslot == 2 ? 0 : rslot + 1;
-                    ++sl;
                     set_slot();
                 }
+                if constexpr (hh == 2 * KT - 1) {
+                    // the head's Q / K biases, read by hand in front of the next half's fragments: the counted wait below
+                    // retires them with this half's fragments, and the epilogue finds them in registers
+                    const unsigned ab = aBias + (unsigned)h * 128u;
+                    bq[0] = q2_read_f32x4<0>(ab); bq[1] = q2_read_f32x4<32>(ab); bq[2] = q2_read_f32x4<64>(ab); bq[3] = q2_read_f32x4<96>(ab);
+                    bk[0] = q2_read_f32x4<H * 4>(ab); bk[1] = q2_read_f32x4<H * 4 + 32>(ab);
+                    bk[2] = q2_read_f32x4<H * 4 + 64>(ab); bk[3] = q2_read_f32x4<H * 4 + 96>(ab);
+                }
                 read_half(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, ntt>{}, std::integral_constant<int, nhalf>{});
-                q2_wait6(F[par]);
+                if constexpr (hh == 2 * KT - 1) q2_wait6_bias(F[par], bq, bk); else q2_wait6(F[par]);
                 static_for<6>([&](auto m_tag) __attribute__((always_inline)) {
-                    constexpr int m = decltype(m_tag)::value, i = m / 3, rb = m % 3;
+                    // order (k-step, matrix) = Q K V Q K V; the head's last half runs Q Q K K V V so that the epilogue of a
+                    // matrix can start under the MFMAs of the next one (each accumulator sees the same order either way)
+                    constexpr int m = decltype(m_tag)::value;
+                    constexpr int i = hh == 2 * KT - 1 ? m % 2 : m / 3, rb = hh == 2 * KT - 1 ? m / 2 : m % 3;
                     constexpr int ks = 2 * hh + i;
                     if constexpr (rb < 2) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[par][i][rb], bf[ks], acc[rb], 0, 0, 0);
                     else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], F[par][i][2], acc[2], 0, 0, 0);
                     // pieces of this half: i0 = ceil(3 hs / 2) .. (3 (hs + 1) + 1) / 2 - 1
                     constexpr int i0 = (3 * hs + 1) / 2, i1 = (3 * (hs + 1) + 1) / 2;
-                    if constexpr (m == 1) dma_piece(sreq, dslot, std::integral_constant<int, i0>{});
-                    if constexpr (m == 4 && i1 - i0 == 2) dma_piece(sreq, dslot, std::integral_constant<int, i0 + 1>{});
+                    if constexpr (m == 1) dma_piece(hnext, std::integral_constant<int, kt / GB>{}, dslot, std::integral_constant<int, i0>{});
+                    if constexpr (m == 4 && i1 - i0 == 2) dma_piece(hnext, std::integral_constant<int, kt / GB>{}, dslot, std::integral_constant<int, i0 + 1>{});
                 });
             });
-            // ---- publish Q_h, K_h (row-major, swizzled) and V_h^T; the last slab barrier above also told us that the
-            // attention waves are done with the previous head's copies
+            // ---- publish Q_h, K_h (row-major, swizzled) and V_h^T in copy h & 1 (the attention waves are two heads behind
+            // at most: they finished head h-2 before they passed "published" of head h-1)
             {
-                const float *bq = BS + h * 32 + 4 * hi, *bk = BS + H + h * 32 + 4 * hi;
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
-                    const f32x4 b0 = *(const f32x4 *)(bq + 8 * gg), b1 = *(const f32x4 *)(bk + 8 * gg);
-                    f16x4 oq, ok;
+                    f16x4 oq;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        oq[e] = (_Float16)(acc[0][4 * gg + e] + b0[e]);
-                        ok[e] = (_Float16)(acc[1][4 * gg + e] + b1[e]);
-                    }
+                    for (int e = 0; e < 4; ++e) oq[e] = (_Float16)(acc[0][4 * gg + e] + bq[gg][e]);
                     *(f16x4 *)(QS + q2_off32(slot, gg) + hi * 8) = oq;
+                }
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    f16x4 ok;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ok[e] = (_Float16)(acc[1][4 * gg + e] + bk[gg][e]);
                     *(f16x4 *)(KS + q2_off32(slot, gg) + hi * 8) = ok;
                 }
-                const float bv = BS[2 * H + h * 32 + l31];
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg) {
                     f16x4 ov;
@@ -242,77 +294,97 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         const float sc = 1.44269504088896340736f / __builtin_sqrtf(32.0f);   // log2(e) / sqrt(d)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the projection waves' first barrier
 
-        f32x16 s[4];
-        float mx = 0.f;
-        auto part1 = [&]() __attribute__((always_inline)) {                // S^T = K Q^T, scale, mask, row maximum
+        if constexpr (Q2_PRIO > 0) __builtin_amdgcn_s_setprio(Q2_PRIO);
+        [[maybe_unused]] const bool tl_sel = tid == 0;
+        // attention of head hh (copy hh & 1 of Q / K / V^T).  WB: the barriers of the head the projection waves work on
+        // meanwhile are executed here, after S-step Q2_P1, after PV-step Q2_P2 and at the end
+        // FAST: every key tile is needed and inside every query's sentence (full windows): straight-line code, no masks
+        auto attend = [&](int hh, auto wb_tag, auto fast_tag, int tb) __attribute__((always_inline)) {
+            constexpr bool WB = decltype(wb_tag)::value, FAST = decltype(fast_tag)::value;
+            const char *QS = QKV + (hh & 1) * QKV_BYTES, *KS = QS + Q2_WIN * 64;
+            const half_t *VT = (const half_t *)(KS + Q2_WIN * 64);
+            f32x16 s[4];
+            // ---- S^T = K Q^T, mask, row maximum (of the raw scores: the scale is positive)
             f16x8 qf[2];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) qf[kk] = *(const f16x8 *)(QS + q2_off32(slot, kk * 2 + hi));
-            mx = -INFINITY;
+            float mx = -INFINITY;
             // (opaque copies: left alone the compiler hoists the 64 mask comparisons out of the head loop into SGPR pairs,
             // spills them to VGPR lanes and reads them back with two v_readlane per element)
             int kb = kbase;
             unsigned kl = klen;
-            asm volatile("" : "+v"(kb), "+v"(kl));
+            if constexpr (!FAST) asm volatile("" : "+v"(kb), "+v"(kl));
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (!(need & (1u << kt))) continue;
+                if (FAST || (need & (1u << kt))) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const f16x8 kf = *(const f16x8 *)(KS + q2_off32(kt * 32 + l31, kk * 2 + hi));
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[kt], 0, 0, 0);
-                }
-                if (inner & (1u << kt)) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = s[kt][r] * sc;
-                        s[kt][r] = v;
-                        mx = fmaxf(mx, v);
+                    for (int kk = 0; kk < 2; ++kk) {
+                        const f16x8 kf = *(const f16x8 *)(KS + q2_off32(kt * 32 + l31, kk * 2 + hi));
+                        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[kt], 0, 0, 0);
                     }
-                } else {
+                    if (FAST || (inner & (1u << kt))) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        // key = kt*32 + (r&3) + 8*(r>>2) + 4*hi is in [k0, k1)
-                        const bool ok = (unsigned)(kt * 32 + (r & 3) + 8 * (r >> 2) + kb) < kl;
-                        const float v = ok ? s[kt][r] * sc : -INFINITY;
-                        s[kt][r] = v;
-                        mx = fmaxf(mx, v);
+                        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            // key = kt*32 + (r&3) + 8*(r>>2) + 4*hi is in [k0, k1)
+                            const bool ok = (unsigned)(kt * 32 + (r & 3) + 8 * (r >> 2) + kb) < kl;
+                            const float v = ok ? s[kt][r] : -INFINITY;
+                            s[kt][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                    }
+                }
+                if constexpr (WB && NBAR == 2) {
+                    if (kt == Q2_P1) {
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 1);
+                        asm volatile("s_barrier" ::: "memory");
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 2);
                     }
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;          // = the maximum of the scaled scores, as attention.hip
             mx = fmaxf(mx, -3.0e38f);                         // empty slots (no keys): keeps exp2(-inf - mx) = 0, no NaN
-        };
-        auto part2 = [&](int hh) __attribute__((always_inline)) {           // softmax, O^T = V^T P^T, normalise, store
+            // ---- softmax (one fma + exp2 per score), O^T = V^T P^T
             float psum = 0.f;
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                if (!(need & (1u << kt))) continue;
+                if (FAST || (need & (1u << kt))) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kt][r] - mx);
-                    s[kt][r] = pv;
-                    psum += pv;
+                    for (int r = 0; r < 16; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -mx));
+                        s[kt][r] = pv;
+                        psum += pv;
+                    }
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        f16x8 pf;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pf[e] = (_Float16)s[kt][8 * st + e];
+                        const int key0 = kt * 32 + 16 * st + 4 * hi;              // keys key0..+3 and key0+8..+11
+                        const half_t *vr = VT + l31 * Q2_VT_LD + key0;
+                        const f16x4 v0 = *(const f16x4 *)vr, v1 = *(const f16x4 *)(vr + 8);
+                        f16x8 vf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                        o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o, 0, 0, 0);
+                    }
                 }
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    f16x8 pf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (_Float16)s[kt][8 * st + e];
-                    const int key0 = kt * 32 + 16 * st + 4 * hi;              // keys key0..+3 and key0+8..+11
-                    const half_t *vr = VT + l31 * Q2_VT_LD + key0;
-                    const f16x4 v0 = *(const f16x4 *)vr, v1 = *(const f16x4 *)(vr + 8);
-                    f16x8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o, 0, 0, 0);
+                if constexpr (WB) {
+                    if (kt == Q2_P2) {
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 3);
+                        asm volatile("s_barrier" ::: "memory");
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 4);
+                    }
                 }
             }
+            // ---- normalise, store
             psum += __shfl_xor(psum, 32);
             if (gtok >= 0) {
                 const float inv = 1.0f / psum;
@@ -321,31 +393,27 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                 for (int gq = 0; gq < 4; ++gq) {
                     f16x4 ov;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(o[4 * gq + e] * inv);
+                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)rounded_f32(o[4 * gq + e] * inv);
                     *(f16x4 *)(op + 8 * gq + 4 * hi) = ov;
                 }
             }
         };
-        // head h is attended while head h+1 is projected: NBAR - 1 slab barriers in the middle, then "done with
-        // Q/K/V^T" (= the projection waves' last slab barrier of the head) and "published"
-        [[maybe_unused]] const bool tl_sel = tid == 0;
-        for (int h = 0; h < n_head; ++h) {
+        const bool fast = need == 0xFu && inner == 0xFu;        // wave-uniform
+        // the projection waves' barriers of head 0 (nothing to attend yet), then head h-1 is attended while head h is
+        // projected, then the last head
+        if constexpr (NBAR == 2) asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        for (int h = 1; h < n_head; ++h) {
             if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h);
-            if (h > 0) part1();
-            if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 1);
-            if constexpr (NBAR == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 2);
-            if (h > 0) part2(h - 1);
-            if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 3);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 4);
-            asm volatile("s_barrier" ::: "memory");
+            if (fast) attend(h - 1, std::true_type{}, std::true_type{}, h);
+            else attend(h - 1, std::true_type{}, std::false_type{}, h);
             if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 5);
+            asm volatile("s_barrier" ::: "memory");             // head h is published
         }
         TL_STAMP_AT(tl_sel, 190);
-        part1();
-        TL_STAMP_AT(tl_sel, 191);
-        part2(n_head - 1);
+        if (fast) attend(n_head - 1, std::false_type{}, std::true_type{}, 0);
+        else attend(n_head - 1, std::false_type{}, std::false_type{}, 0);
         TL_STAMP_AT(tl_sel, 192);
     }
 }
@@ -367,7 +435,7 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
     a.spw = qkv_attention2_sentences_per_window(max_len);
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;
-    const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2 + (size_t)3 * Wqkv.K * sizeof(float);
+    const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * Wqkv.K * sizeof(float);
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
