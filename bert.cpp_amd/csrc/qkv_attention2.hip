@@ -14,9 +14,11 @@
 //               softmax over the keys of the query's own sentence, O^T = V^T P^T, normalise, store (as attention.hip).
 // Wave a and wave a+4 share a SIMD: the projection MFMAs run under the softmax VALU work, and every SIMD carries the
 // same number of MFMAs (72 + 16 per head).  Q_h / K_h / V_h^T are double-buffered in LDS (head h in buffer h & 1), so
-// the projection waves never wait for the attention of the previous head; per head the two groups meet at NBAR+1
-// barriers — the slab barriers and "Q/K/V^T of this head are published" — which the attention waves execute at
-// matching points of their own work (Q2_P1 / Q2_P2) so that neither group waits long for the other.
+// the projection waves never wait for the attention of the previous head; per head the two groups meet at two barriers:
+// the slab barrier in the middle of the head and, at its end, the barrier that both opens the next head's first slab and
+// publishes Q/K/V^T.  The attention waves execute the first one in the middle of their own work (Q2_PM).  In the head's
+// last k-tile the MFMAs run matrix by matrix (Q, then K, then V), so that the conversion of Q and K to f16 overlaps
+// with the remaining MFMAs.
 //
 // Windows and bit-exactness: sentence j of the window starts at slot off_j with off_0 = 0, off_{j+1} = off_j + n_j
 // rounded up to 16.  A softmax row only ever sees the keys of its own sentence (the others are masked with -inf before
@@ -27,13 +29,10 @@
 // masked at all.
 #include "tile_stream.h"
 
-// tuning knobs (A/B builds): the attention waves execute the head's first barrier after S-step Q2_P1 and the second after
-// PV-step Q2_P2 (steps 0..3 = key tiles); Q2_PRIO = s_setprio level of the attention waves
-#ifndef Q2_P1
-#define Q2_P1 2
-#endif
-#ifndef Q2_P2
-#define Q2_P2 1
+// tuning knobs (A/B builds): the attention waves execute the head's first barrier after step Q2_PM of their 8 steps
+// (0..3 = S^T key tiles, 4..7 = P V key tiles); Q2_PRIO = s_setprio level of the attention waves
+#ifndef Q2_PM
+#define Q2_PM 3
 #endif
 #ifndef Q2_PRIO
 #define Q2_PRIO 0
@@ -78,9 +77,14 @@ __device__ __forceinline__ void q2_slab_barrier(f16x8 (&f)[2][3]) {
     asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
                  : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]) : "n"(VM) : "memory");
 }
-// the same wait, also handing over the eight hand-read bias vectors (older than the six reads left in flight)
-__device__ __forceinline__ void q2_wait6_bias(f16x8 (&f)[2][3], f32x4 (&bq)[4], f32x4 (&bk)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(6)"
+// all but the newest fourteen reads have landed (the last half's six fragment reads and the eight bias vectors behind them)
+__device__ __forceinline__ void q2_wait14(f16x8 (&f)[2][3]) {
+    asm volatile("s_waitcnt lgkmcnt(14)"
+                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]) : : "memory");
+}
+// every read has landed: the last half's fragments and the bias vectors
+__device__ __forceinline__ void q2_wait0_bias(f16x8 (&f)[2][3], f32x4 (&bq)[4], f32x4 (&bk)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]),
                    "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]), "+v"(bk[0]), "+v"(bk[1]), "+v"(bk[2]), "+v"(bk[3]) : : "memory");
 }
@@ -90,15 +94,12 @@ __device__ __forceinline__ f32x4 q2_read_f32x4(unsigned addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
     return v;
 }
-// last slab barrier of a head: also hands over the V bias (a global load older than every DMA piece that may stay in flight)
+// hands over the V bias (an untracked global load older than every DMA piece that is still in flight at the head's first barrier)
+__device__ __forceinline__ void q2_take(float &bv) { asm volatile("" : "+v"(bv)); }
+// end of a head: Q/K/V^T are written, this wave's pieces of the next head's first slab have landed (all but the newest VM)
 template <int VM>
-__device__ __forceinline__ void q2_slab_barrier_bias(f16x8 (&f)[2][3], float &bv) {
-    asm volatile("s_waitcnt vmcnt(%7) lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]), "+v"(bv) : "n"(VM) : "memory");
-}
-__device__ __forceinline__ void q2_publish_barrier(f16x8 (&f)[2][3]) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[0][2]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[1][2]) : : "memory");
+__device__ __forceinline__ void q2_head_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(VM) : "memory");
 }
 
 }  // namespace
@@ -108,7 +109,7 @@ template <int KT, int GB>
 __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 64 * KT, NBAR = KT / GB, SLAB = GB * Q2_TILE, PPS = 3 * GB;   // PPS = DMA pieces per slab and wave
-    static_assert(KT % GB == 0 && NBAR >= 1 && NBAR <= 2, "");
+    static_assert(KT == 2 * GB && NBAR == 2, "");
     constexpr int QKV_BYTES = 2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2;   // Q [128][32] + K [128][32] (q2_off32 swizzle) + V^T [32][Q2_VT_LD]
     char *RING = smem;                                        // 3 slabs
     char *QKV = smem + 3 * SLAB;                              // two copies: head h in copy h & 1
@@ -119,12 +120,32 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int blk = wave & 3;                                 // token block (projection) / query block (attention)
     const int n_head = a.n_head;
+    TL_STAMP_AT(tid == 256, 120);
+    TL_REALTIME_AT(tid == 256, 121);
+    TL_STAMP_AT(tid == 0, 250);
+    TL_REALTIME_AT(tid == 0, 251);
+
+    // ---- weight DMA of the projection waves: piece i of a slab for wave slot wp = tile i / 3, row block rb = i % 3 (Q, K, V
+    // rows), rows wp*8 .. +8 of it.  Slab 0 is requested before anything else
+    const int wp = blk;
+    const unsigned loff = (unsigned)(((wp * 8 + (lane >> 3)) * H + (((lane & 7) ^ (((wp & 1) << 2) | ((lane >> 4) & 3))) * 8)) * 2);
+    // piece i of slab j (compile time) of the head whose Q rows start at `hbase`
+    auto dma_piece = [&](const char *hbase, auto j_tag, int dslot, auto i_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value, t = i / 3, rb = i % 3;
+        const char *src = hbase + ((size_t)rb * H * H + (size_t)(j * GB + t) * 64) * 2;
+        __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + loff), AS_LDS(RING + dslot * SLAB + t * Q2_TILE + rb * 4096 + wp * 1024), 16, 0, 0);
+    };
+    const char *const wbase = (const char *)a.w;
+    if (wave >= 4) static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, 0>{}, 0, i); });
 
     // ---- the window: sentences first .. first+count-1, sentence j at slots [off_j, off_j + n_j)
     int first, count;
     if (a.groups) { const int2 g = a.groups[blockIdx.x]; first = g.x; count = g.y; }
     else { first = blockIdx.x * a.spw; count = min(a.spw, a.n_sent - first); }
-    if (count <= 0) return;
+    if (count <= 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (never taken by the launcher's grids) the DMA must not outlive the workgroup
+        return;
+    }
     const int slot = blk * 32 + l31;
     int gtok = -1, k0 = 0, k1 = 0;                            // this lane's slot: global token, key range of its sentence
     {
@@ -135,30 +156,20 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             off = (off + n + 15) & ~15;
         }
     }
-    for (int i = tid; i < 2 * H; i += 512) BS[i] = a.bias[i];
 
     if (wave >= 4) {
         // =============================== projection wave: token block `blk` ===============================
-        const int wp = blk;
         // rows of the hidden state as MFMA fragments (token = l31, k = 16 ks + 8 hi ..): B operand of the Q / K
         // projections, A operand of the V projection.  Empty slots read the window's first token (finite values).
         f16x8 bf[4 * KT];
         {
             const int gt = gtok >= 0 ? gtok : a.cu[first];
             const half_t *xr = a.x + (size_t)gt * H + 8 * hi;
+            // (untracked loads: the first barrier waits for them and for slab 0 only, slab 1 stays in flight)
 #pragma unroll
-            for (int ks = 0; ks < 4 * KT; ++ks) bf[ks] = *(const f16x8 *)(xr + 16 * ks);
+            for (int ks = 0; ks < 4 * KT; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[ks]) : "v"(xr + 16 * ks));
         }
-        // DMA: piece (i) of a slab for this wave = tile i / 3, row block rb = i % 3 (Q, K, V rows), rows wp*8 .. +8 of it
-        const unsigned loff = (unsigned)(((wp * 8 + (lane >> 3)) * H + (((lane & 7) ^ (((wp & 1) << 2) | ((lane >> 4) & 3))) * 8)) * 2);
-        // piece i of slab j (compile time) of the head whose Q rows start at `hbase`
-        auto dma_piece = [&](const char *hbase, auto j_tag, int dslot, auto i_tag) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value, t = i / 3, rb = i % 3;
-            const char *src = hbase + ((size_t)rb * H * H + (size_t)(j * GB + t) * 64) * 2;
-            __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + loff), AS_LDS(RING + dslot * SLAB + t * Q2_TILE + rb * 4096 + wp * 1024), 16, 0, 0);
-        };
-        const char *const wbase = (const char *)a.w;
-        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, 0>{}, 0, i); });
+        // (slab 0 was requested at kernel entry) slab 1 behind the x rows: the first barrier leaves it in flight
         static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, NBAR - 1>{}, 1, i); });
         // per-lane LDS address of the weight fragment of k-step kk of a tile: the chunk swizzle is an XOR of 2*kk + hi
         const unsigned aX0 = lds_addr(RING) + off64(l31, hi);
@@ -180,10 +191,12 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                 F[par][i][2] = q2_read_b128<tt * Q2_TILE + 8192>(aS[2 * half + i]);
             }
         };
-        // x rows, slab 0 and (compiler: the ordinary loads above are waited for with vmcnt(0)) slab 1 have landed
+        // x rows and slab 0 have landed (slab 1 may still be in flight)
         [[maybe_unused]] const bool tl_sel = tid == 256;
         TL_STAMP_AT(tl_sel, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(PPS) : "memory");
+#pragma unroll
+        for (int ks = 0; ks < 4 * KT; ++ks) asm volatile("" : "+v"(bf[ks]));
         TL_STAMP_AT(tl_sel, 1);
         read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
@@ -203,76 +216,96 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+            constexpr int LT0 = 2 * KT - 2, LT1 = 2 * KT - 1;      // the halves of the head's last k-tile
+            auto pieces = [&](auto hh_tag, auto m_tag) __attribute__((always_inline)) {
+                // the pieces of the slab after next go behind MFMAs 1 and 4 of a half (piece i in half (2 i) / 3 of the slab),
+                // into the slot the previous slab was read from
+                constexpr int hh = decltype(hh_tag)::value, m = decltype(m_tag)::value, hs = hh % (2 * GB);
+                constexpr int i0 = (3 * hs + 1) / 2, i1 = (3 * (hs + 1) + 1) / 2;
+                const int dslot = (hh == 2 * GB - 1) ? (rslot == 2 ? 0 : rslot + 1) : (rslot == 0 ? 2 : rslot - 1);
+                if constexpr (m == 1) dma_piece(hnext, std::integral_constant<int, (hh >> 1) / GB>{}, dslot, std::integral_constant<int, i0>{});
+                if constexpr (m == 4 && i1 - i0 == 2) dma_piece(hnext, std::integral_constant<int, (hh >> 1) / GB>{}, dslot, std::integral_constant<int, i0 + 1>{});
+            };
+            auto mma = [&](auto par_tag, auto i_tag, auto rb_tag, auto ks_tag) __attribute__((always_inline)) {
+                constexpr int par = decltype(par_tag)::value, i = decltype(i_tag)::value, rb = decltype(rb_tag)::value, ks = decltype(ks_tag)::value;
+                if constexpr (rb < 2) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[par][i][rb], bf[ks], acc[rb], 0, 0, 0);
+                else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], F[par][i][2], acc[2], 0, 0, 0);
+            };
             static_for<2 * KT>([&](auto hh_tag) __attribute__((always_inline)) {
-                constexpr int hh = decltype(hh_tag)::value, kt = hh >> 1, half = hh & 1, par = hh & 1;
-                constexpr int nhh = (hh + 1) % (2 * KT), ntt = (nhh >> 1) % GB, nhalf = nhh & 1;
-                constexpr bool crossing = half == 1 && (kt + 1) % GB == 0;        // the next half opens a new slab
-                constexpr int hs = hh % (2 * GB);                                  // half index inside the slab
-                // the pieces of slab sl+2 go behind the MFMAs of slab sl (piece i in half (2 i) / 3 of the slab), into the
-                // slot slab sl-1 was read from.  (Taken before the crossing update: this half still belongs to slab sl.)
-                const int dslot = rslot == 0 ? 2 : rslot - 1;
-                if constexpr (crossing) {
-                    if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + (hh == 2 * KT - 1 ? 2 : 0));
-                    // outstanding here, oldest first: the next slab (complete), then the slab after it WITHOUT the one
-                    // piece this last half is about to request
-                    if constexpr (hh == 2 * KT - 1) q2_slab_barrier_bias<PPS - 1>(F[par], bv);
-                    else q2_slab_barrier<PPS - 1>(F[par]);
-                    if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + (hh == 2 * KT - 1 ? 3 : 1));
+                constexpr int hh = decltype(hh_tag)::value, par = hh & 1;
+                constexpr int nhh = hh + 1, ntt = (nhh >> 1) % GB, nhalf = nhh & 1;
+                using PAR = std::integral_constant<int, par>;
+                if constexpr (hh == 2 * GB - 1) {
+                    // the slab barrier in the middle of the head sits in front of the first slab's last half.  Outstanding here,
+                    // oldest first: the V bias, the second slab (complete), then the next head's first slab WITHOUT the one
+                    // piece this half is about to request
+                    if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h);
+                    q2_slab_barrier<PPS - 1>(F[par]);
+                    if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 1);
+                    q2_take(bv);
                     rslot = rslot == 2 ? 0 : rslot + 1;
                     set_slot();
                 }
-                if constexpr (hh == 2 * KT - 1) {
-                    // the head's Q / K biases, read by hand in front of the next half's fragments: the counted wait below
-                    // retires them with this half's fragments, and the epilogue finds them in registers
+                if constexpr (hh < LT1) read_half(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, ntt>{}, std::integral_constant<int, nhalf>{});
+                if constexpr (hh < LT0) {
+                    q2_wait6(F[par]);
+                    static_for<6>([&](auto m_tag) __attribute__((always_inline)) {      // k-step by k-step: Q K V Q K V
+                        constexpr int m = decltype(m_tag)::value;
+                        mma(PAR{}, std::integral_constant<int, m / 3>{}, std::integral_constant<int, m % 3>{}, std::integral_constant<int, 2 * hh + m / 3>{});
+                        pieces(hh_tag, m_tag);
+                    });
+                } else if constexpr (hh == LT0) {
+                    // the head's Q / K biases, read by hand behind the last half's fragments: they land under this half's MFMAs
                     const unsigned ab = aBias + (unsigned)h * 128u;
                     bq[0] = q2_read_f32x4<0>(ab); bq[1] = q2_read_f32x4<32>(ab); bq[2] = q2_read_f32x4<64>(ab); bq[3] = q2_read_f32x4<96>(ab);
                     bk[0] = q2_read_f32x4<H * 4>(ab); bk[1] = q2_read_f32x4<H * 4 + 32>(ab);
                     bk[2] = q2_read_f32x4<H * 4 + 64>(ab); bk[3] = q2_read_f32x4<H * 4 + 96>(ab);
+                    q2_wait14(F[par]);
+                    static_for<6>([&](auto m_tag) __attribute__((always_inline)) {      // last k-tile, matrix by matrix: Q Q K K V V ...
+                        constexpr int m = decltype(m_tag)::value;
+                        mma(PAR{}, std::integral_constant<int, m % 2>{}, std::integral_constant<int, m / 2>{}, std::integral_constant<int, 2 * hh + m % 2>{});
+                        pieces(hh_tag, m_tag);
+                    });
+                } else {
+                    q2_wait0_bias(F[par], bq, bk);
+                    // ... Q Q (Q is complete: its conversion runs under the K and V MFMAs) K K (the same for K) V V
+                    static_for<2>([&](auto i) __attribute__((always_inline)) { mma(PAR{}, i, std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * hh + decltype(i)::value>{}); });
+                    pieces(hh_tag, std::integral_constant<int, 1>{});
+                    static_for<2>([&](auto i) __attribute__((always_inline)) { mma(PAR{}, i, std::integral_constant<int, 1>{}, std::integral_constant<int, 2 * hh + decltype(i)::value>{}); });
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        f16x4 oq;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) oq[e] = (_Float16)(acc[0][4 * gg + e] + bq[gg][e]);
+                        *(f16x4 *)(QS + q2_off32(slot, gg) + hi * 8) = oq;
+                    }
+                    static_for<2>([&](auto i) __attribute__((always_inline)) { mma(PAR{}, i, std::integral_constant<int, 2>{}, std::integral_constant<int, 2 * hh + decltype(i)::value>{}); });
+                    pieces(hh_tag, std::integral_constant<int, 4>{});
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        f16x4 ok;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ok[e] = (_Float16)(acc[1][4 * gg + e] + bk[gg][e]);
+                        *(f16x4 *)(KS + q2_off32(slot, gg) + hi * 8) = ok;
+                    }
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        f16x4 ov;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(acc[2][4 * gg + e] + bv);
+                        *(f16x4 *)(VT + l31 * Q2_VT_LD + blk * 32 + 8 * gg + 4 * hi) = ov;
+                    }
                 }
-                read_half(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, ntt>{}, std::integral_constant<int, nhalf>{});
-                if constexpr (hh == 2 * KT - 1) q2_wait6_bias(F[par], bq, bk); else q2_wait6(F[par]);
-                static_for<6>([&](auto m_tag) __attribute__((always_inline)) {
-                    // order (k-step, matrix) = Q K V Q K V; the head's last half runs Q Q K K V V so that the epilogue of a
-                    // matrix can start under the MFMAs of the next one (each accumulator sees the same order either way)
-                    constexpr int m = decltype(m_tag)::value;
-                    constexpr int i = hh == 2 * KT - 1 ? m % 2 : m / 3, rb = hh == 2 * KT - 1 ? m / 2 : m % 3;
-                    constexpr int ks = 2 * hh + i;
-                    if constexpr (rb < 2) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[par][i][rb], bf[ks], acc[rb], 0, 0, 0);
-                    else acc[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks], F[par][i][2], acc[2], 0, 0, 0);
-                    // pieces of this half: i0 = ceil(3 hs / 2) .. (3 (hs + 1) + 1) / 2 - 1
-                    constexpr int i0 = (3 * hs + 1) / 2, i1 = (3 * (hs + 1) + 1) / 2;
-                    if constexpr (m == 1) dma_piece(hnext, std::integral_constant<int, kt / GB>{}, dslot, std::integral_constant<int, i0>{});
-                    if constexpr (m == 4 && i1 - i0 == 2) dma_piece(hnext, std::integral_constant<int, kt / GB>{}, dslot, std::integral_constant<int, i0 + 1>{});
-                });
             });
-            // ---- publish Q_h, K_h (row-major, swizzled) and V_h^T in copy h & 1 (the attention waves are two heads behind
-            // at most: they finished head h-2 before they passed "published" of head h-1)
-            {
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    f16x4 oq;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) oq[e] = (_Float16)(acc[0][4 * gg + e] + bq[gg][e]);
-                    *(f16x4 *)(QS + q2_off32(slot, gg) + hi * 8) = oq;
-                }
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    f16x4 ok;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ok[e] = (_Float16)(acc[1][4 * gg + e] + bk[gg][e]);
-                    *(f16x4 *)(KS + q2_off32(slot, gg) + hi * 8) = ok;
-                }
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    f16x4 ov;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)(acc[2][4 * gg + e] + bv);
-                    *(f16x4 *)(VT + l31 * Q2_VT_LD + blk * 32 + 8 * gg + 4 * hi) = ov;
-                }
-            }
+            // ---- Q_h, K_h (row-major, swizzled) and V_h^T are in copy h & 1 (the attention waves are two heads behind at
+            // most: they finished head h-2 before they passed the end of head h-1).  One barrier publishes them and opens the
+            // next head's first slab; in flight behind it: this wave's pieces of the next head's second slab
             if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 4);
-            q2_publish_barrier(F[0]);
+            q2_head_barrier<PPS>();
             if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 5);
+            rslot = rslot == 2 ? 0 : rslot + 1;
+            set_slot();
+            read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
         }
         TL_STAMP_AT(tl_sel, 60);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the dead prefetches must not outlive the LDS allocation
@@ -292,12 +325,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         const unsigned klen = (unsigned)(k1 - k0);
         const int kbase = 4 * hi - k0;
         const float sc = 1.44269504088896340736f / __builtin_sqrtf(32.0f);   // log2(e) / sqrt(d)
+        for (int i = tid; i < 2 * H; i += 256) BS[i] = a.bias[i];             // Q and K bias -> LDS (these waves have nothing else to do yet)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the projection waves' first barrier
 
         if constexpr (Q2_PRIO > 0) __builtin_amdgcn_s_setprio(Q2_PRIO);
         [[maybe_unused]] const bool tl_sel = tid == 0;
-        // attention of head hh (copy hh & 1 of Q / K / V^T).  WB: the barriers of the head the projection waves work on
-        // meanwhile are executed here, after S-step Q2_P1, after PV-step Q2_P2 and at the end
+        // attention of head hh (copy hh & 1 of Q / K / V^T).  WB: the slab barrier of the head the projection waves work on
+        // meanwhile is executed here, after step Q2_PM
         // FAST: every key tile is needed and inside every query's sentence (full windows): straight-line code, no masks
         auto attend = [&](int hh, auto wb_tag, auto fast_tag, int tb) __attribute__((always_inline)) {
             constexpr bool WB = decltype(wb_tag)::value, FAST = decltype(fast_tag)::value;
@@ -338,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                         }
                     }
                 }
-                if constexpr (WB && NBAR == 2) {
-                    if (kt == Q2_P1) {
+                if constexpr (WB) {
+                    if (kt == Q2_PM) {
                         if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 1);
                         asm volatile("s_barrier" ::: "memory");
                         if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 2);
@@ -377,10 +411,10 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                     }
                 }
                 if constexpr (WB) {
-                    if (kt == Q2_P2) {
-                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 3);
+                    if (kt + 4 == Q2_PM) {
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 1);
                         asm volatile("s_barrier" ::: "memory");
-                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 4);
+                        if (tb < 8) TL_STAMP_AT(tl_sel, 128 + 6 * tb + 2);
                     }
                 }
             }
@@ -401,7 +435,6 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         const bool fast = need == 0xFu && inner == 0xFu;        // wave-uniform
         // the projection waves' barriers of head 0 (nothing to attend yet), then head h-1 is attended while head h is
         // projected, then the last head
-        if constexpr (NBAR == 2) asm volatile("s_barrier" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
         for (int h = 1; h < n_head; ++h) {
@@ -409,12 +442,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             if (fast) attend(h - 1, std::true_type{}, std::true_type{}, h);
             else attend(h - 1, std::true_type{}, std::false_type{}, h);
             if (h < 8) TL_STAMP_AT(tl_sel, 128 + 6 * h + 5);
-            asm volatile("s_barrier" ::: "memory");             // head h is published
+            asm volatile("s_barrier" ::: "memory");             // end of head h: it is published
         }
         TL_STAMP_AT(tl_sel, 190);
         if (fast) attend(n_head - 1, std::false_type{}, std::true_type{}, 0);
         else attend(n_head - 1, std::false_type{}, std::false_type{}, 0);
         TL_STAMP_AT(tl_sel, 192);
+        TL_STAMP_AT(tl_sel, 252);
+        TL_REALTIME_AT(tl_sel, 253);
     }
 }
 
@@ -439,7 +474,7 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
-        TL_DUMP_RAW(grid >= 256, 200);
+        TL_DUMP_RAW(grid >= 256, 256);
     };
     switch (KT) {
         case 2: go(qkv_attention2_kernel<2, 1>); break;

@@ -36,6 +36,8 @@ __device__ __forceinline__ void static_for(F &&f) { static_for_impl(std::make_in
 static __device__ unsigned long long g_timeline[1024 * 256];
 #define TL_STAMP(i) do { const int tl_i = (i); if (threadIdx.x == 0 && tl_i < 256) g_timeline[(blockIdx.x & 1023) * 256 + tl_i] = __builtin_readcyclecounter(); } while (0)
 #define TL_STAMP_AT(sel, i) do { const int tl_i = (i); if ((sel) && tl_i < 256) g_timeline[(blockIdx.x & 1023) * 256 + tl_i] = __builtin_readcyclecounter(); } while (0)
+// the constant 100 MHz counter next to the shader clock: (cycles between two stamps) / (real time between them) = the clock
+#define TL_REALTIME_AT(sel, i) do { const int tl_i = (i); if ((sel) && tl_i < 256) g_timeline[(blockIdx.x & 1023) * 256 + tl_i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define TL_DUMP(cond, nstamps) do {                                                                          \
     static int tl_shots = 0;                                                                                  \
     if ((cond) && tl_shots++ == 20) {                                                                         \
@@ -67,6 +69,7 @@ static __device__ unsigned long long g_timeline[1024 * 256];
 } while (0)
 #else
 #define TL_DUMP_RAW(cond, nstamps) do { } while (0)
+#define TL_REALTIME_AT(sel, i) do { } while (0)
 #define TL_STAMP(i) do { } while (0)
 #define TL_STAMP_AT(sel, i) do { } while (0)
 #define TL_DUMP(cond, nstamps) do { } while (0)
