@@ -189,10 +189,13 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
                        hipStream_t s) {
     const int n_pad = (max_len + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const size_t lds = (size_t)n_pad * D * 2 + (size_t)D * (n_pad + VT_PAD) * 2;
-    static size_t configured = 0;
-    if (lds > 64 * 1024 && lds > configured) {
-        hipFuncSetAttribute((const void *)attention_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
+    static size_t configured[MAX_HIP_DEVICES] = {};           // per device: the opt-in is a per-device attribute
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= MAX_HIP_DEVICES - 1;
+    if (lds > 64 * 1024 && lds > configured[dev]) {
+        (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured[dev] = lds;
     }
     hipLaunchKernelGGL((attention_mfma_kernel<D>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }

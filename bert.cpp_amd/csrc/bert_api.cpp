@@ -19,8 +19,14 @@
 
 #include "../../include/bert.h"
 #include "../../include/bert_hip.h"
+#include <exception>
+#include <new>
+#include <system_error>
+#include <utility>
+
 #include "engine.h"
 #include "model_file.h"
+#include "multi_device.h"
 #include "tokenizer.h"
 
 using namespace bert_hip;
@@ -28,7 +34,13 @@ using namespace bert_hip;
 struct bert_ctx {
     HParams hp;
     Tokenizer tok;
-    std::unique_ptr<Engine> engine;   // null for tokenizer-only contexts
+    // one engine (weight replica + stream + workspace) per GPU; empty for tokenizer-only contexts.  Devices:
+    // BERT_HIP_DEVICES ("all" or a comma-separated list), else BERT_HIP_DEVICE (one ordinal), else every visible device
+    std::vector<std::unique_ptr<Engine>> engines;
+    Engine *engine() const { return engines.empty() ? nullptr : engines[0].get(); }
+    // device-resident results of bert_hip_eval_packed_gather: shard buffers and the gathered matrix, per device
+    std::vector<std::unique_ptr<DevBuf>> shard_out, gathered;
+    RcclGather rccl;
 };
 
 namespace {
@@ -36,6 +48,60 @@ namespace {
 bool quiet_env() {
     const char *q = getenv("BERT_HIP_QUIET");
     return q && *q && *q != '0';
+}
+
+// No exception may cross the C ABI: every extern "C" entry runs its body through one of these; an
+// exception (std::bad_alloc from a staging vector, std::system_error from a thread, ...) becomes the reference's error
+// convention — a line on stderr and an early return with the outputs untouched.
+template <class F>
+auto guarded(const char *name, decltype(std::declval<F>()()) on_error, F &&body) -> decltype(body()) {
+    try {
+        return body();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s: %s\n", name, e.what());
+    } catch (...) {
+        fprintf(stderr, "%s: unknown exception\n", name);
+    }
+    return on_error;
+}
+template <class F>
+void guarded_void(const char *name, F &&body) {
+    try {
+        body();
+    } catch (const std::exception &e) {
+        fprintf(stderr, "%s: %s\n", name, e.what());
+    } catch (...) {
+        fprintf(stderr, "%s: unknown exception\n", name);
+    }
+}
+
+// the devices a context spreads over (see bert_ctx)
+bool context_devices(std::vector<int> &devs, std::string &err) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        err = "no HIP device available (this library needs an AMD GPU; there is no CPU fallback)";
+        return false;
+    }
+    const char *list = getenv("BERT_HIP_DEVICES"), *one = getenv("BERT_HIP_DEVICE");
+    devs.clear();
+    if (list && *list && strcmp(list, "all") != 0) {
+        for (const char *p = list; *p;) {
+            char *end = nullptr;
+            const long d = strtol(p, &end, 10);
+            if (end == p) { err = std::string("BERT_HIP_DEVICES: cannot parse '") + list + "'"; return false; }
+            if (d < 0 || d >= ndev) { err = "BERT_HIP_DEVICES: ordinal " + std::to_string(d) + " out of range"; return false; }
+            devs.push_back((int)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+    } else if ((!list || !*list) && one && *one) {
+        const int d = atoi(one);
+        if (d < 0 || d >= ndev) { err = "BERT_HIP_DEVICE out of range"; return false; }
+        devs.push_back(d);
+    } else {
+        for (int d = 0; d < ndev; ++d) devs.push_back(d);
+    }
+    if (devs.empty()) { err = "BERT_HIP_DEVICES names no device"; return false; }
+    return true;
 }
 
 bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
@@ -59,15 +125,22 @@ bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
     ctx->tok.build(std::move(mf.vocab));
     ctx->tok.quiet = quiet;           // BERT_HIP_QUIET also drops the reference's per-byte "unknown token" stderr lines
     if (!tokenizer_only) {
-        Engine *e = Engine::create(mf, err);
-        if (!e) {
+        std::vector<int> devs;
+        if (!context_devices(devs, err)) {
             fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
             return nullptr;
         }
-        ctx->engine.reset(e);
+        for (int d : devs) {
+            Engine *e = Engine::create(mf, d, err);
+            if (!e) {
+                fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
+                return nullptr;
+            }
+            ctx->engines.emplace_back(e);
+        }
         if (!quiet)
-            printf("%s: model size = %8.2f MB / num tensors = %zu (HBM-resident on HIP device %d)\n", "bert_load_from_file",
-                   mf.total_tensor_bytes / 1024.0 / 1024.0, mf.tensors.size(), e->device());
+            printf("%s: model size = %8.2f MB / num tensors = %zu (HBM-resident on %zu HIP device%s, first %d)\n", "bert_load_from_file",
+                   mf.total_tensor_bytes / 1024.0 / 1024.0, mf.tensors.size(), devs.size(), devs.size() == 1 ? "" : "s", devs[0]);
     }
     return ctx.release();
 }
@@ -90,6 +163,32 @@ bool sentence_ok(const bert_ctx *ctx, const bert_vocab_id *toks, int32_t n) {
     return true;
 }
 
+// One packed batch over all devices of the context: contiguous token-balanced shards, one host thread per device, every
+// shard's embeddings written straight into the caller's rows (or, d_dst: into the shard's device buffer).  Batches of
+// fewer than MIN_SHARD_TOKENS tokens per device stay on the first device (a launch sequence costs ~50 us whatever the size).
+constexpr long long MIN_SHARD_TOKENS = 2048;
+int eval_packed_all_devices(bert_ctx *ctx, const int32_t *tokens, const int32_t *cu, int B, float *embeddings, std::string &err,
+                            std::vector<int> *bounds_out = nullptr, float *const *d_dst = nullptr) {
+    const int H = ctx->hp.n_embd;
+    int n_dev = (int)ctx->engines.size();
+    const long long total = (long long)cu[B] - cu[0];
+    if (!d_dst)
+        while (n_dev > 1 && total < MIN_SHARD_TOKENS * n_dev) --n_dev;
+    std::vector<int> bounds;
+    shard_bounds(cu, B, n_dev, bounds);
+    if (bounds_out) *bounds_out = bounds;
+    std::vector<std::string> errs((size_t)n_dev);
+    const int rc = dispatch_shards(bounds, [&](int r, int b0, int b1) {
+        // eval_packed_host takes the global token array and a window of the prefix sums
+        return ctx->engines[r]->eval_packed_host(tokens, cu + b0, b1 - b0, embeddings ? embeddings + (size_t)b0 * H : nullptr, errs[r],
+                                                 d_dst ? d_dst[r] : nullptr);
+    });
+    if (rc != 0)
+        for (auto &e : errs)
+            if (!e.empty()) { err = e; break; }
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -107,14 +206,15 @@ bool bert_params_parse(int argc, char **argv, bert_params &params) {
         fprintf(stderr, "  -m FNAME, --model FNAME\n                        model path (default: %s)\n\n", params.model);
     };
     for (int i = 1; i < argc; ++i) {
-        const std::string arg = argv[i];
+        const char *arg = argv[i];
         const bool has_value = i + 1 < argc;
-        if ((arg == "-t" || arg == "--threads") && has_value) params.n_threads = atoi(argv[++i]);
-        else if ((arg == "-p" || arg == "--prompt") && has_value) params.prompt = argv[++i];
-        else if (arg == "--port" && has_value) params.port = atoi(argv[++i]);
-        else if ((arg == "-m" || arg == "--model") && has_value) params.model = argv[++i];
+        auto is = [&](const char *a, const char *b) { return strcmp(arg, a) == 0 || strcmp(arg, b) == 0; };
+        if (is("-t", "--threads") && has_value) params.n_threads = atoi(argv[++i]);
+        else if (is("-p", "--prompt") && has_value) params.prompt = argv[++i];
+        else if (strcmp(arg, "--port") == 0 && has_value) params.port = atoi(argv[++i]);
+        else if (is("-m", "--model") && has_value) params.model = argv[++i];
         else {
-            if (arg != "-h" && arg != "--help") fprintf(stderr, "error: unknown argument: %s\n", arg.c_str());
+            if (!is("-h", "--help")) fprintf(stderr, "error: unknown argument: %s\n", arg);
             usage();
             exit(0);   // the reference exits with status 0 on both paths (bert.cpp:180-189)
         }
@@ -122,23 +222,29 @@ bool bert_params_parse(int argc, char **argv, bert_params &params) {
     return true;
 }
 
-struct bert_ctx *bert_load_from_file(const char *fname) { return load_impl(fname, false); }
+struct bert_ctx *bert_load_from_file(const char *fname) {
+    return guarded("bert_load_from_file", (bert_ctx *)nullptr, [&] { return load_impl(fname, false); });
+}
 
-void bert_free(struct bert_ctx *ctx) { delete ctx; }
+void bert_free(struct bert_ctx *ctx) {
+    guarded_void("bert_free", [&] { delete ctx; });
+}
 
 int32_t bert_n_embd(struct bert_ctx *ctx) { return ctx->hp.n_embd; }
 int32_t bert_n_max_tokens(struct bert_ctx *ctx) { return ctx->hp.n_max_tokens; }
 const char *bert_vocab_id_to_token(struct bert_ctx *ctx, bert_vocab_id id) { return ctx->tok.id_to_token(id); }
 
 void bert_tokenize(struct bert_ctx *ctx, const char *text, bert_vocab_id *tokens, int32_t *n_tokens, int32_t n_max_tokens) {
-    ctx->tok.tokenize(text, tokens, n_tokens, n_max_tokens);
+    guarded_void("bert_tokenize", [&] { ctx->tok.tokenize(text, tokens, n_tokens, n_max_tokens); });
 }
 
 // returns the number of sentences evaluated (stops in front of the first one it cannot handle), -1 on a device error
 static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_vocab_id *const *batch_tokens,
                                const int32_t *n_tokens, float *const *batch_embeddings) {
-    if (!ctx->engine) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
+    if (!ctx->engine()) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
     if (n_batch_size <= 0) return 0;
+    if (const char *inj = getenv("BERT_HIP_INJECT_BAD_ALLOC"))   // test knob: the path an exhausted host takes
+        if (*inj == '1') throw std::bad_alloc();
     // The reference evaluates sentences in order and stops at the first one it cannot handle,
     // leaving later outputs untouched; keep that observable behaviour.
     int32_t B = 0;
@@ -152,7 +258,7 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
     const int H = ctx->hp.n_embd;
     std::vector<float> out((size_t)B * H);
     std::string err;
-    if (ctx->engine->eval_packed_host(packed.data(), cu.data(), B, out.data(), err) != 0) {
+    if (eval_packed_all_devices(ctx, packed.data(), cu.data(), B, out.data(), err) != 0) {
         fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
         return -1;
     }
@@ -163,7 +269,7 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
 void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batch_size, bert_vocab_id **batch_tokens,
                      int32_t *n_tokens, float **batch_embeddings) {
     if (!batch_embeddings) return;   // the reference's memory-probe mode (bert.cpp:739); nothing to size here
-    (void)eval_batch_impl(ctx, n_batch_size, batch_tokens, n_tokens, batch_embeddings);
+    guarded_void("bert_eval_batch", [&] { (void)eval_batch_impl(ctx, n_batch_size, batch_tokens, n_tokens, batch_embeddings); });
 }
 
 void bert_eval(struct bert_ctx *ctx, int32_t n_threads, bert_vocab_id *tokens, int32_t n_tokens, float *embeddings) {
@@ -190,15 +296,19 @@ static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inpu
             for (int32_t i = i0; i < i1; ++i) ctx->tok.tokenize(texts[i], tokens + (size_t)i * N, &n_tokens[i], N);
         }
     };
+    // a thread that cannot be started is not an error: the others (at least the caller) take its share
     std::vector<std::thread> pool;
-    for (int k = 1; k < nt; ++k) pool.emplace_back(work);
+    try {
+        for (int k = 1; k < nt; ++k) pool.emplace_back(work);
+    } catch (const std::system_error &) {
+    }
     work();
     for (auto &th : pool) th.join();
 }
 
-void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batch_size*/, int32_t n_inputs,
-                       const char **texts, float **embeddings) {
-    if (n_inputs <= 0) return;
+// number of inputs encoded (stops at the first failure, later outputs untouched)
+static int32_t encode_batch_impl(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts, float **embeddings) {
+    if (n_inputs <= 0) return 0;
     const int32_t N = ctx->hp.n_max_tokens;
     // Tokenize on n_threads host threads (at 10^5 sentences/s on the GPU the tokenizer is the stage in front of the
     // path that has to keep up) and evaluate as packed device batches (the reference sorts by length and loops with
@@ -218,21 +328,33 @@ void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batc
         tokenize_many(ctx, n_threads, n, texts + i0, g.ids.data(), g.n_tokens.data());
     };
     tokenize_group(groups[0], 0, std::min(GROUP, n_inputs));
+    int32_t total = 0;
     for (int32_t i0 = 0, k = 0; i0 < n_inputs; i0 += GROUP, ++k) {
         const int32_t n = std::min(GROUP, n_inputs - i0), n_next = std::min(GROUP, n_inputs - i0 - n);
         std::thread ahead;
-        if (n_next > 0) ahead = std::thread([&, k, i0, n, n_next] { tokenize_group(groups[(k + 1) & 1], i0 + n, n_next); });
-        const int32_t done = eval_batch_impl(ctx, n, groups[k & 1].ptrs.data(), groups[k & 1].n_tokens.data(), embeddings + i0);
-        if (ahead.joinable()) ahead.join();
-        if (done != n) return;                                // outputs after the failure stay untouched
+        std::exception_ptr ahead_error;
+        if (n_next > 0) {
+            auto job = [&, k, i0, n, n_next] {
+                try { tokenize_group(groups[(k + 1) & 1], i0 + n, n_next); } catch (...) { ahead_error = std::current_exception(); }
+            };
+            try { ahead = std::thread(job); } catch (const std::system_error &) { job(); }     // no thread: tokenize in line
+        }
+        int32_t done = -1;
+        std::exception_ptr eval_error;
+        try { done = eval_batch_impl(ctx, n, groups[k & 1].ptrs.data(), groups[k & 1].n_tokens.data(), embeddings + i0); }
+        catch (...) { eval_error = std::current_exception(); }
+        if (ahead.joinable()) ahead.join();                   // never leave the scope with a running thread
+        if (eval_error) std::rethrow_exception(eval_error);
+        if (ahead_error) std::rethrow_exception(ahead_error);
+        total += done > 0 ? done : 0;
+        if (done != n) break;                                 // outputs after the failure stay untouched
     }
+    return total;
 }
 
-int32_t bert_hip_tokenize_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
-                                bert_vocab_id *tokens, int32_t *n_tokens) {
-    if (!ctx || n_inputs < 0 || (n_inputs > 0 && (!texts || !tokens || !n_tokens))) return -1;
-    tokenize_many(ctx, n_threads, n_inputs, texts, tokens, n_tokens);
-    return 0;
+void bert_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t /*n_batch_size*/, int32_t n_inputs,
+                       const char **texts, float **embeddings) {
+    guarded_void("bert_encode_batch", [&] { (void)encode_batch_impl(ctx, n_threads, n_inputs, texts, embeddings); });
 }
 
 void bert_encode(struct bert_ctx *ctx, int32_t n_threads, const char *texts, float *embeddings) {
@@ -242,73 +364,184 @@ void bert_encode(struct bert_ctx *ctx, int32_t n_threads, const char *texts, flo
 // ------------------------------------------------------------------------------------------------
 // bert_hip.h
 // ------------------------------------------------------------------------------------------------
-struct bert_ctx *bert_hip_load_tokenizer(const char *fname) { return load_impl(fname, true); }
+struct bert_ctx *bert_hip_load_tokenizer(const char *fname) {
+    return guarded("bert_hip_load_tokenizer", (bert_ctx *)nullptr, [&] { return load_impl(fname, true); });
+}
+
+int32_t bert_hip_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts, float **embeddings) {
+    return guarded("bert_hip_encode_batch", (int32_t)-1, [&] { return encode_batch_impl(ctx, n_threads, n_inputs, texts, embeddings); });
+}
+
+int32_t bert_hip_tokenize_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
+                                bert_vocab_id *tokens, int32_t *n_tokens) {
+    if (!ctx || n_inputs < 0 || (n_inputs > 0 && (!texts || !tokens || !n_tokens))) return -1;
+    return guarded("bert_hip_tokenize_batch", (int32_t)-1, [&] { tokenize_many(ctx, n_threads, n_inputs, texts, tokens, n_tokens); return (int32_t)0; });
+}
 
 int32_t bert_hip_n_layer(struct bert_ctx *ctx) { return ctx->hp.n_layer; }
 int32_t bert_hip_n_head(struct bert_ctx *ctx) { return ctx->hp.n_head; }
 int32_t bert_hip_n_intermediate(struct bert_ctx *ctx) { return ctx->hp.n_intermediate; }
 int32_t bert_hip_n_vocab(struct bert_ctx *ctx) { return ctx->hp.n_vocab; }
 int32_t bert_hip_ftype(struct bert_ctx *ctx) { return ctx->hp.f16; }
-int32_t bert_hip_device(struct bert_ctx *ctx) { return ctx->engine ? ctx->engine->device() : -1; }
+int32_t bert_hip_device(struct bert_ctx *ctx) { return ctx->engine() ? ctx->engine()->device() : -1; }
+int32_t bert_hip_n_devices(struct bert_ctx *ctx) { return (int32_t)ctx->engines.size(); }
 
 int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens, const int32_t *cu_seqlens,
                              int32_t n_sentences, float *embeddings) {
-    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_packed: tokenizer-only context\n"); return -1; }
-    for (int32_t b = 0; b < n_sentences; ++b)
-        if (!sentence_ok(ctx, tokens + cu_seqlens[b], cu_seqlens[b + 1] - cu_seqlens[b])) return -2;
-    std::string err;
-    if (ctx->engine->eval_packed_host(tokens, cu_seqlens, n_sentences, embeddings, err) != 0) {
-        fprintf(stderr, "bert_hip_eval_packed: %s\n", err.c_str());
-        return -3;
-    }
-    return 0;
+    return guarded("bert_hip_eval_packed", (int32_t)-4, [&]() -> int32_t {
+        if (!ctx->engine()) { fprintf(stderr, "bert_hip_eval_packed: tokenizer-only context\n"); return -1; }
+        if (n_sentences <= 0) return 0;
+        for (int32_t b = 0; b < n_sentences; ++b)
+            if (!sentence_ok(ctx, tokens + cu_seqlens[b], cu_seqlens[b + 1] - cu_seqlens[b])) return -2;
+        std::string err;
+        if (eval_packed_all_devices(ctx, tokens, cu_seqlens, n_sentences, embeddings, err) != 0) {
+            fprintf(stderr, "bert_hip_eval_packed: %s\n", err.c_str());
+            return -3;
+        }
+        return 0;
+    });
+}
+
+int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *tokens, const int32_t *cu_seqlens,
+                                    int32_t n_sentences, float **d_embeddings) {
+    return guarded("bert_hip_eval_packed_gather", (int32_t)-4, [&]() -> int32_t {
+        if (!ctx->engine()) { fprintf(stderr, "bert_hip_eval_packed_gather: tokenizer-only context\n"); return -1; }
+        if (n_sentences <= 0) return 0;
+        for (int32_t b = 0; b < n_sentences; ++b)
+            if (!sentence_ok(ctx, tokens + cu_seqlens[b], cu_seqlens[b + 1] - cu_seqlens[b])) return -2;
+        const int n_dev = (int)ctx->engines.size(), H = ctx->hp.n_embd;
+        std::string err;
+        // per device: a buffer for its own shard and the gathered [n_sentences][H] matrix (grow-only, owned by the context)
+        if (ctx->shard_out.empty())
+            for (int d = 0; d < n_dev; ++d) { ctx->shard_out.emplace_back(new DevBuf); ctx->gathered.emplace_back(new DevBuf); }
+        std::vector<int> bounds;
+        shard_bounds(cu_seqlens, n_sentences, n_dev, bounds);
+        std::vector<float *> src((size_t)n_dev), dst((size_t)n_dev);
+        std::vector<hipStream_t> streams((size_t)n_dev);
+        for (int d = 0; d < n_dev; ++d) {
+            if (hipSetDevice(ctx->engines[d]->device()) != hipSuccess) { fprintf(stderr, "bert_hip_eval_packed_gather: hipSetDevice failed\n"); return -3; }
+            // (a single device gathers nothing: its shard buffer IS the result)
+            if (!ctx->shard_out[d]->ensure((size_t)std::max(1, bounds[d + 1] - bounds[d]) * H * 4, err) ||
+                (n_dev > 1 && !ctx->gathered[d]->ensure((size_t)n_sentences * H * 4, err))) {
+                fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
+                return -3;
+            }
+            src[d] = ctx->shard_out[d]->as<float>();
+            dst[d] = n_dev > 1 ? ctx->gathered[d]->as<float>() : src[d];
+            streams[d] = ctx->engines[d]->stream();
+        }
+        if (eval_packed_all_devices(ctx, tokens, cu_seqlens, n_sentences, nullptr, err, nullptr, src.data()) != 0) {
+            fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
+            return -3;
+        }
+        // the one exchange step of the path: every device receives every other device's shard (RCCL over xGMI).  With
+        // BERT_HIP_RCCL_SINGLE=1 a single device runs it too (a 1-rank communicator), to exercise the code on one GPU.
+        const char *force = getenv("BERT_HIP_RCCL_SINGLE");
+        if (n_dev > 1 || (force && *force == '1')) {
+            std::vector<int> devs;
+            for (auto &e : ctx->engines) devs.push_back(e->device());
+            if (n_dev == 1) {
+                if (!ctx->gathered[0]->ensure((size_t)n_sentences * H * 4, err)) { fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str()); return -3; }
+                dst[0] = ctx->gathered[0]->as<float>();
+            }
+            if (!ctx->rccl.init(devs, err) || !ctx->rccl.all_gather(src.data(), dst.data(), bounds, H, streams.data(), err)) {
+                fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
+                return -3;
+            }
+        }
+        for (int d = 0; d < n_dev; ++d) {
+            if (hipSetDevice(ctx->engines[d]->device()) != hipSuccess || hipStreamSynchronize(streams[d]) != hipSuccess) {
+                fprintf(stderr, "bert_hip_eval_packed_gather: synchronisation failed\n");
+                return -3;
+            }
+            d_embeddings[d] = dst[d];
+        }
+        return 0;
+    });
 }
 
 int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens, const int32_t *d_cu_seqlens,
                                     int32_t n_sentences, int32_t n_tokens_total, int32_t max_len, float *d_embeddings,
                                     void *stream) {
-    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_packed_device: tokenizer-only context\n"); return -1; }
-    if (max_len > ctx->hp.n_max_tokens) { fprintf(stderr, "Too many tokens, maximum is %d\n", ctx->hp.n_max_tokens); return -2; }
-    std::string err;
-    if (ctx->engine->eval_packed_device(d_tokens, d_cu_seqlens, n_sentences, n_tokens_total, max_len, d_embeddings,
-                                        (hipStream_t)stream, nullptr, err) != 0) {
-        fprintf(stderr, "bert_hip_eval_packed_device: %s\n", err.c_str());
-        return -3;
-    }
-    return 0;
+    return guarded("bert_hip_eval_packed_device", (int32_t)-4, [&]() -> int32_t {
+        if (!ctx->engine()) { fprintf(stderr, "bert_hip_eval_packed_device: tokenizer-only context\n"); return -1; }
+        if (max_len > ctx->hp.n_max_tokens) { fprintf(stderr, "Too many tokens, maximum is %d\n", ctx->hp.n_max_tokens); return -2; }
+        if (max_len <= 0 || n_tokens_total > (long long)n_sentences * max_len) {
+            fprintf(stderr, "bert_hip_eval_packed_device: max_len = %d cannot hold %d tokens in %d sentences\n", max_len, n_tokens_total, n_sentences);
+            return -2;
+        }
+        std::string err;
+        if (ctx->engine()->eval_packed_device(d_tokens, d_cu_seqlens, n_sentences, n_tokens_total, max_len, d_embeddings,
+                                              (hipStream_t)stream, nullptr, err) != 0) {
+            fprintf(stderr, "bert_hip_eval_packed_device: %s\n", err.c_str());
+            return -3;
+        }
+        return 0;
+    });
+}
+
+int32_t bert_hip_reserve(struct bert_ctx *ctx, int32_t n_tokens, int32_t n_sentences) {
+    return guarded("bert_hip_reserve", (int32_t)-4, [&]() -> int32_t {
+        std::string err;
+        for (auto &e : ctx->engines)
+            if (!e->reserve(n_tokens, n_sentences, err)) { fprintf(stderr, "bert_hip_reserve: %s\n", err.c_str()); return -3; }
+        return 0;
+    });
+}
+
+int32_t bert_hip_check(struct bert_ctx *ctx) {
+    return guarded("bert_hip_check", (int32_t)-4, [&]() -> int32_t {
+        int32_t st = 0;
+        std::string err;
+        for (auto &e : ctx->engines) {
+            const int s = e->check(err);
+            if (s < 0) { fprintf(stderr, "bert_hip_check: %s\n", err.c_str()); return -3; }
+            st |= s;
+        }
+        if (st) fprintf(stderr, "bert_hip_check: a device batch held a sentence longer than the max_len it was called with (or an empty one): its embeddings are NaN\n");
+        return st;
+    });
 }
 
 int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id *tokens, int32_t n_tokens, float *hidden,
                              float *embedding) {
-    if (!ctx->engine) { fprintf(stderr, "bert_hip_eval_hidden: tokenizer-only context\n"); return -1; }
-    if (!sentence_ok(ctx, tokens, n_tokens)) return -2;
-    std::string err;
-    if (ctx->engine->eval_hidden(tokens, n_tokens, hidden, embedding, err) != 0) {
-        fprintf(stderr, "bert_hip_eval_hidden: %s\n", err.c_str());
-        return -3;
-    }
-    return 0;
+    return guarded("bert_hip_eval_hidden", (int32_t)-4, [&]() -> int32_t {
+        if (!ctx->engine()) { fprintf(stderr, "bert_hip_eval_hidden: tokenizer-only context\n"); return -1; }
+        if (!sentence_ok(ctx, tokens, n_tokens)) return -2;
+        std::string err;
+        if (ctx->engine()->eval_hidden(tokens, n_tokens, hidden, embedding, err) != 0) {
+            fprintf(stderr, "bert_hip_eval_hidden: %s\n", err.c_str());
+            return -3;
+        }
+        return 0;
+    });
 }
 
 void bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on) {
-    if (ctx->engine) ctx->engine->profile_enable(on != 0);
+    guarded_void("bert_hip_profile_enable", [&] { for (auto &e : ctx->engines) e->profile_enable(on != 0); });
 }
 
 int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len) {
-    if (!ctx->engine) return 0;
-    const std::string r = ctx->engine->profile_report();
-    if (buf && buf_len > 0) {
-        const size_t n = std::min((size_t)buf_len - 1, r.size());
-        memcpy(buf, r.data(), n);
-        buf[n] = 0;
-    }
-    return (int32_t)r.size();
+    return guarded("bert_hip_profile_report", (int32_t)0, [&]() -> int32_t {
+        if (!ctx->engine()) return 0;
+        const std::string r = ctx->engine()->profile_report();      // (the first device's kernels)
+        for (size_t d = 1; d < ctx->engines.size(); ++d) (void)ctx->engines[d]->profile_report();
+        if (buf && buf_len > 0) {
+            const size_t n = std::min((size_t)buf_len - 1, r.size());
+            memcpy(buf, r.data(), n);
+            buf[n] = 0;
+        }
+        return (int32_t)r.size();
+    });
 }
 
 void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value) {
-    if (ctx->engine && key && value) ctx->engine->set_option(key, value);
+    guarded_void("bert_hip_set_option", [&] {
+        if (key && value)
+            for (auto &e : ctx->engines) e->set_option(key, value);
+    });
 }
 
-const char *bert_hip_version(void) { return "bert.cpp_amd 0.1 (gfx950)"; }
+const char *bert_hip_version(void) { return "bert.cpp_amd 0.2 (gfx950)"; }
 
 }  // extern "C"

@@ -49,12 +49,14 @@ struct KernelStat { int launches = 0; double ms = 0.0; double flops = 0.0; };
 
 class Engine {
 public:
-    static Engine *create(const ModelFile &mf, std::string &err);
+    // device: HIP ordinal the weights are uploaded to and every launch runs on
+    static Engine *create(const ModelFile &mf, int device, std::string &err);
     ~Engine();
 
     // host-resident packed batch (validated by the caller), blocking
+    // embeddings: host destination [n_sentences][H]; d_embeddings (optional, instead): destination in this device's memory
     int eval_packed_host(const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, float *embeddings,
-                         std::string &err);
+                         std::string &err, float *d_embeddings = nullptr);
     // device-resident, asynchronous on `stream`
     // d_windows / n_windows: optional sentence windows of the fused projection+attention kernel (build_windows), in
     // device memory; without them sentences are placed by the uniform rule of qkv_attention2.hip
@@ -67,12 +69,18 @@ public:
     static void build_windows(const int32_t *cu_seqlens, int n_sentences, std::vector<int2> &windows);
     int eval_hidden(const int32_t *tokens, int n_tokens, float *hidden, float *embedding, std::string &err);
 
+    // sizes the workspace for batches of up to n_tokens tokens / n_sentences sentences now, so that later calls of
+    // eval_packed_device never allocate (allocation synchronises the device and breaks stream capture)
+    bool reserve(int n_tokens, int n_sentences, std::string &err);
+    // device-side validation (sentence lengths vs max_len): synchronises, returns and clears the status word
+    int check(std::string &err);
     void set_option(const std::string &key, const std::string &value);
     void profile_enable(bool on);
     std::string profile_report();
 
     const HParams &hparams() const { return hp_; }
     int device() const { return device_; }
+    hipStream_t stream() const { return stream_; }
 
 private:
     Engine() = default;
@@ -86,8 +94,10 @@ private:
     std::vector<LayerWeights *> layers_;
 
     // workspace (grow-only)
-    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_;
+    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_, status_;
     hipStream_t stream_ = nullptr;
+    // the workspace serves ONE forward pass at a time: every pass waits for the previous one's event on its own stream
+    hipEvent_t busy_ = nullptr;
     // host path: two sets of pinned staging + device id / embedding buffers, so that the host stages chunk i+1 and
     // unpacks chunk i-1 while the GPU computes chunk i (eval_packed_host)
     struct HostSlot {

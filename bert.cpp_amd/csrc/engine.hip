@@ -165,20 +165,17 @@ static bool concat_upload(DevBuf &b, std::initializer_list<const HostTensor *> t
     return b.upload(all.data(), all.size(), err);
 }
 
-Engine *Engine::create(const ModelFile &mf, std::string &err) {
+Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         err = "no HIP device available (this library needs an AMD GPU; there is no CPU fallback)";
         return nullptr;
     }
+    if (device < 0 || device >= ndev) { err = "HIP device ordinal " + std::to_string(device) + " out of range"; return nullptr; }
     Engine *e = new Engine;
     e->hp_ = mf.hp;
-    const char *dv = getenv("BERT_HIP_DEVICE");
-    if (dv && *dv) {
-        e->device_ = atoi(dv);
-        if (e->device_ < 0 || e->device_ >= ndev) { err = "BERT_HIP_DEVICE out of range"; delete e; return nullptr; }
-        if (hipSetDevice(e->device_) != hipSuccess) { err = "hipSetDevice failed"; delete e; return nullptr; }
-    } else if (hipGetDevice(&e->device_) != hipSuccess) { err = "hipGetDevice failed"; delete e; return nullptr; }
+    e->device_ = device;
+    if (hipSetDevice(e->device_) != hipSuccess) { err = "hipSetDevice failed"; delete e; return nullptr; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, e->device_) != hipSuccess) { err = "hipGetDeviceProperties failed"; delete e; return nullptr; }
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
@@ -227,7 +224,9 @@ Engine *Engine::create(const ModelFile &mf, std::string &err) {
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
     }
+    ok = ok && e->status_.alloc(16, err);
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
+    if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
     if (!ok) { delete e; return nullptr; }
     return e;
 }
@@ -245,12 +244,35 @@ Engine::~Engine() {
         if (sl.h_windows) (void)hipHostFree(sl.h_windows);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
+    if (busy_) (void)hipEventDestroy(busy_);
     if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+bool Engine::reserve(int n_tokens, int n_sentences, std::string &err) {
+    HIP_OK(hipSetDevice(device_), err, false);
+    if (n_tokens <= 0 || n_sentences <= 0) return true;
+    return ensure_workspace((n_tokens + GEMM_BM - 1) / GEMM_BM * GEMM_BM, n_sentences, err);
+}
+
+int Engine::check(std::string &err) {
+    HIP_OK(hipSetDevice(device_), err, -1);
+    HIP_OK(hipDeviceSynchronize(), err, -1);
+    int st = 0;
+    HIP_OK(hipMemcpy(&st, status_.p, sizeof(int), hipMemcpyDeviceToHost), err, -1);
+    if (st) HIP_OK(hipMemset(status_.p, 0, sizeof(int)), err, -1);
+    return st;
 }
 
 void Engine::set_option(const std::string &key, const std::string &value) {
     if (key == "gemm") {
-        gemm_naive_ = value == "naive";
+        // the generic kernel reads GemmWeight::naive16, an image that is only built at load time (BERT_HIP_GEMM=naive) or
+        // for shapes the MFMA kernels cannot take: refuse the switch when a matrix lacks it
+        bool have = true;
+        for (auto *L : layers_)
+            for (GemmWeightStore *w : {&L->qkv, &L->o, &L->ffi, &L->ffo}) have = have && w->w.naive16 != nullptr;
+        if (value == "naive" && !have)
+            fprintf(stderr, "bert_hip_set_option: gemm=naive needs BERT_HIP_GEMM=naive at load time (the f16 row-major images were not built); ignored\n");
+        else gemm_naive_ = value == "naive";
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "ffn") ffn_fused_ = value != "unfused";
     else if (key == "panel") panel_ = value != "0";
@@ -329,6 +351,8 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
     const int t_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
     if (!ensure_workspace(t_pad, B, err)) return -1;
+    // one forward pass at a time on the shared workspace: wait (on the caller's stream) for the previous pass
+    HIP_OK(hipStreamWaitEvent(s, busy_, 0), err, -1);
     half_t *x = x_.as<half_t>(), *qkv = qkv_.as<half_t>(), *ctx = ctx_.as<half_t>(), *y = y_.as<half_t>(),
            *ff = ff_.as<half_t>();
     const double Td = (double)T;
@@ -336,7 +360,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
                     half_t *C, int epi) {
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (W.mfma_ok && !gemm_naive_) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (W.mfma_ok && (!gemm_naive_ || !W.w.naive16)) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
     };
@@ -412,9 +436,10 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         }
         tap(il + 1);
     }
-    timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, d_out, s); });
+    timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, max_len, status_.as<int>(), d_out, s); });
     (void)I;
     HIP_OK(hipGetLastError(), err, -1);
+    HIP_OK(hipEventRecord(busy_, s), err, -1);
     return 0;
 }
 
@@ -428,7 +453,8 @@ static bool ensure_pinned(void **p, size_t *cap, size_t need, std::string &err) 
     return true;
 }
 
-int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, float *embeddings, std::string &err) {
+int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, float *embeddings, std::string &err,
+                             float *d_embeddings) {
     if (B <= 0) return 0;
     HIP_OK(hipSetDevice(device_), err, -1);
     const int H = hp_.n_embd;
@@ -464,7 +490,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     auto unpack = [&](size_t i) -> bool {
         HostSlot &sl = slot_[i & 1];
         if (hipEventSynchronize(sl.done) != hipSuccess) { err = "hipEventSynchronize failed"; return false; }
-        memcpy(embeddings + (size_t)chunks[i].b0 * H, sl.h_out, (size_t)(chunks[i].b1 - chunks[i].b0) * H * 4);
+        if (!d_embeddings) memcpy(embeddings + (size_t)chunks[i].b0 * H, sl.h_out, (size_t)(chunks[i].b1 - chunks[i].b0) * H * 4);
         return true;
     };
     auto fail = [&]() { (void)hipStreamSynchronize(stream_); return -1; };        // nothing may stay queued on the slots
@@ -489,7 +515,8 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         if (eval_packed_device(sl.d_tokens.as<int32_t>(), sl.d_cu.as<int32_t>(), nb, T, chunks[i].max_len, sl.d_out.as<float>(),
                                stream_, nullptr, err, n_windows ? sl.d_windows.as<int2>() : nullptr, n_windows) != 0)
             return fail();
-        if (hipMemcpyAsync(sl.h_out, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_) != hipSuccess ||
+        if ((d_embeddings ? hipMemcpyAsync(d_embeddings + (size_t)b0 * H, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToDevice, stream_)
+                          : hipMemcpyAsync(sl.h_out, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_)) != hipSuccess ||
             hipEventRecord(sl.done, stream_) != hipSuccess) {
             err = "hipMemcpyAsync (embeddings) failed";
             return fail();

@@ -103,9 +103,21 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
                            int n_sentences, const int2 *groups, int n_groups, int max_len, int n_head, half_t *out,
                            hipStream_t stream);
 
-// mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].
-void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
-                           hipStream_t stream);
+// mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].  A sentence whose length is not in
+// [1, max_len] (the caller of the device API promised max_len) gets a NaN row and sets *status (device word) to 1.
+void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status,
+                           float *out, hipStream_t stream);
+
+// The > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) is per device: `seen` is the launcher's per-kernel record.
+constexpr int MAX_HIP_DEVICES = 64;
+inline bool first_launch_on_device(bool (&seen)[MAX_HIP_DEVICES]) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    d &= MAX_HIP_DEVICES - 1;
+    if (seen[d]) return false;
+    seen[d] = true;
+    return true;
+}
 
 // f16 [rows][cols] -> f32 (hidden-state tap)
 void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream);

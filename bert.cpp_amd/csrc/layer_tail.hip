@@ -696,11 +696,10 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
     a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out; a.I = W1.N;
     const int H = W1.K, NT = H / 128;
     const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + a.I + 64) * sizeof(float);
-    static bool configured[4] = {};
+    static bool configured[4][MAX_HIP_DEVICES] = {};
     auto go = [&](auto kernel) __attribute__((always_inline)) {
-        if (!configured[NT]) {
+        if (first_launch_on_device(configured[NT])) {
             (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured[NT] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(256), lds, stream, a);
         TL_DUMP(M_pad >= 128 * 256, 200);

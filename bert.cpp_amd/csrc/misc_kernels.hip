@@ -250,10 +250,17 @@ void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, i
 // One workgroup per sentence; wave w sums tokens w, w+4, ... over coalesced half2 row reads, the
 // four partial rows are combined through LDS.
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, const int32_t *cu_seqlens, int H,
-                                                             float *out) {
+                                                             int max_len, int *status, float *out) {
     extern __shared__ float part[];          // [4][H] partial sums, then red[4]
     const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
+    if (n <= 0 || n > max_len) {
+        // the batch does not keep the caller's promise (bert_hip_eval_packed_device: max_len): the kernels upstream were
+        // chosen and sized for max_len, so this sentence's result is not trustworthy -> NaN row, status word
+        for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] = __builtin_nanf("");
+        if (tid == 0 && status) atomicOr(status, 1);
+        return;
+    }
     const float invn = 1.0f / (float)n;
     if (H % 8 == 0) {
         // 16-byte runs per lane (same per-element summation order as the pair loop below)
@@ -295,11 +302,11 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, co
     for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] = part[e] * scale;
 }
 
-void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, float *out,
-                           hipStream_t stream) {
+void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status,
+                           float *out, hipStream_t stream) {
     if (n_sentences <= 0) return;
     hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_sentences), dim3(256), (4 * H + 4) * sizeof(float), stream, x,
-                       cu_seqlens, H, out);
+                       cu_seqlens, H, max_len, status, out);
 }
 
 __global__ void f16_to_f32_kernel(const half_t *src, float *dst, size_t n) {

@@ -1,0 +1,42 @@
+// multi_device.h — one bert_ctx over several GPUs of a node: the sentences of a call are independent
+// (the reference evaluates them in a sequential loop, bert.cpp:750), so a call is cut into contiguous shards with
+// near-equal token counts, one per device; every device holds a replica of the weights and evaluates its shard on its
+// own host thread and stream.  Results go straight to the caller's host rows (bert.h API), or stay on the devices and
+// are exchanged by ONE RCCL step so that every device holds the whole [n_sentences][n_embd] matrix (bert_hip.h API).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace bert_hip {
+
+// bounds[r] .. bounds[r+1]: sentences of shard r (n_shards + 1 entries, bounds[0] = 0, bounds[n_shards] = n_sentences).
+// Shards are contiguous, in order, balanced by TOKEN count; a shard may be empty.  Same rule as bert.cpp_amd/dist.py.
+void shard_bounds(const int32_t *cu_seqlens, int n_sentences, int n_shards, std::vector<int> &bounds);
+
+// eval(shard, first, last) for every non-empty shard: shard 0 on the calling thread, the others on threads of their own.
+// Returns 0, or the first non-zero result.
+int dispatch_shards(const std::vector<int> &bounds, const std::function<int(int, int, int)> &eval);
+
+// RCCL (librccl.so, loaded on first use: libbert.so has no link-time dependency on it), one communicator per device.
+class RcclGather {
+public:
+    ~RcclGather();
+    bool init(const std::vector<int> &devices, std::string &err);
+    bool ready() const { return !comms_.empty(); }
+    // src[r]: shard r on device r ((bounds[r+1] - bounds[r]) * H floats); dst[d]: [n_sentences][H] on device d.  One
+    // grouped exchange (a broadcast per shard: the shards differ in size) on the devices' streams; not synchronised.
+    bool all_gather(float *const *src, float *const *dst, const std::vector<int> &bounds, int H, hipStream_t *streams,
+                    std::string &err);
+
+private:
+    void *lib_ = nullptr;
+    std::vector<void *> comms_;
+    std::vector<int> devices_;
+    void *fn_[8] = {};
+};
+
+}  // namespace bert_hip

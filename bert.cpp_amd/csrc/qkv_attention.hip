@@ -434,11 +434,10 @@ void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *
     a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.out = out; a.n_head = n_head;
     const int KT = Wqkv.K / 64;
     const size_t lds = (size_t)KT * 16384 + 9 * QA_WSLOT + 2 * QA_TOK * 64 + 32 * QA_VT_LD * 2;
-    static bool configured[3][7] = {};
+    static bool configured[3][7][MAX_HIP_DEVICES] = {};
     auto go = [&](auto kernel) {
-        if (!configured[Wqkv.type][KT]) {
+        if (first_launch_on_device(configured[Wqkv.type][KT])) {
             (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured[Wqkv.type][KT] = true;
         }
         hipLaunchKernelGGL(kernel, dim3(n_sentences), dim3(512), lds, stream, a);
         TL_DUMP(n_sentences >= 256, 136);

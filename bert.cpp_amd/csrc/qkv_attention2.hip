@@ -471,8 +471,10 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;
     const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * Wqkv.K * sizeof(float);
+    static bool configured[8][MAX_HIP_DEVICES] = {};
     auto go = [&](auto kernel) {
-        (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (first_launch_on_device(configured[KT]))
+            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
         TL_DUMP_RAW(grid >= 256, 256);
     };

@@ -4,8 +4,9 @@
 #include <string>
 #include <vector>
 
-#include "../../include/bert_hip.h"
+#include "../../include/bert_hip_test.h"
 #include "engine.h"
+#include "multi_device.h"
 
 using namespace bert_hip;
 
@@ -271,6 +272,38 @@ int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(out, dout.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
     return 0;
+}
+
+
+void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards, int32_t *bounds) {
+    std::vector<int> b;
+    shard_bounds(cu_seqlens, n_sentences, n_shards, b);
+    for (size_t i = 0; i < b.size(); ++i) bounds[i] = b[i];
+}
+
+int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows) {
+    std::vector<int2> w;
+    Engine::build_windows(cu_seqlens, n_sentences, w);
+    for (size_t i = 0; i < w.size(); ++i) { windows[2 * i] = w[i].x; windows[2 * i + 1] = w[i].y; }
+    return (int32_t)w.size();
+}
+
+int32_t bert_hip_test_dispatch(const bert_vocab_id *tokens, const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards,
+                               int32_t H, float *out) {
+    std::vector<int> bounds;
+    shard_bounds(cu_seqlens, n_sentences, n_shards, bounds);
+    return dispatch_shards(bounds, [&](int shard, int b0, int b1) {
+        // stands in for Engine::eval_packed_host(tokens, cu + b0, b1 - b0, out + b0 * H): the global token array and a
+        // window of the prefix sums, results into the caller's rows of this shard
+        const int32_t *cu = cu_seqlens + b0;
+        float *dst = out + (size_t)b0 * H;
+        for (int b = 0; b < b1 - b0; ++b) {
+            long long sum = 0;
+            for (int t = cu[b]; t < cu[b + 1]; ++t) sum += tokens[t];
+            for (int e = 0; e < H; ++e) dst[(size_t)b * H + e] = e == 0 ? (float)sum : e == 1 ? (float)(cu[b + 1] - cu[b]) : e == 2 ? (float)shard : (float)(b0 + b);
+        }
+        return 0;
+    });
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "bert.h"
+#include "bert_hip.h"
 
 namespace {
 
@@ -120,15 +122,20 @@ int main(int argc, char **argv) {
                 text_ptrs[r] = texts[r].c_str();
                 out_ptrs[r] = out.data() + (size_t)r * n_embd;
             }
-            bert_encode_batch(ctx, params.n_threads, n, n, text_ptrs.data(), out_ptrs.data());
+            // bert_hip_encode_batch = bert_encode_batch with a result: the requests it could not evaluate (device error) get
+            // no reply at all — their connections are closed instead of being sent the zero-filled rows
+            const int32_t done = bert_hip_encode_batch(ctx, params.n_threads, n, text_ptrs.data(), out_ptrs.data());
             for (int32_t r = 0; r < n; ++r)
-                if (!send_all(fds[owners[r]].fd, out_ptrs[r], sizeof(float) * (size_t)n_embd)) closing.push_back(owners[r]);
+                if (r >= done || !send_all(fds[owners[r]].fd, out_ptrs[r], sizeof(float) * (size_t)n_embd)) closing.push_back(owners[r]);
         }
 
         if (fds[0].revents & POLLIN) {
             int c = accept(listener, nullptr, nullptr);
             if (c >= 0) {
                 setsockopt(c, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+                // one client that stops reading must not stall the others: a send that blocks for 2 s fails, the client is dropped
+                timeval tv{2, 0};
+                setsockopt(c, SOL_SOCKET, SO_SNDTIMEO, &tv, sizeof(tv));
                 if (send_all(c, &n_embd, sizeof(n_embd))) {
                     fds.push_back({c, POLLIN, 0});
                     printf("New connection\n");

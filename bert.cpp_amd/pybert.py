@@ -22,11 +22,17 @@ BERT_H_SYMBOLS = [
 ]
 BERT_HIP_H_SYMBOLS = [
     "bert_hip_load_tokenizer", "bert_hip_tokenize_batch", "bert_hip_n_layer", "bert_hip_n_head", "bert_hip_n_intermediate", "bert_hip_n_vocab",
-    "bert_hip_ftype", "bert_hip_device", "bert_hip_eval_packed", "bert_hip_eval_packed_device", "bert_hip_eval_hidden",
-    "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_test_gemm",
-    "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
-    "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_version",
+    "bert_hip_ftype", "bert_hip_device", "bert_hip_n_devices", "bert_hip_encode_batch", "bert_hip_eval_packed", "bert_hip_eval_packed_gather",
+    "bert_hip_eval_packed_device", "bert_hip_reserve", "bert_hip_check", "bert_hip_eval_hidden",
+    "bert_hip_profile_enable", "bert_hip_profile_report", "bert_hip_set_option", "bert_hip_version",
 ]
+# include/bert_hip_test.h: the op-level test hooks, exported by libbert_test.so only
+BERT_HIP_TEST_H_SYMBOLS = [
+    "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
+    "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
+    "bert_hip_test_dispatch",
+]
+TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so"
 
 
 def build(force: bool = False, jobs: int = 8) -> str:
@@ -71,6 +77,32 @@ def lib() -> C.CDLL:
     L.bert_hip_profile_enable.restype = None; L.bert_hip_profile_enable.argtypes = [vp, i32]
     L.bert_hip_profile_report.restype = i32; L.bert_hip_profile_report.argtypes = [vp, C.c_char_p, i32]
     L.bert_hip_set_option.restype = None; L.bert_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.bert_hip_n_devices.restype = i32; L.bert_hip_n_devices.argtypes = [vp]
+    L.bert_hip_encode_batch.restype = i32
+    L.bert_hip_encode_batch.argtypes = [vp, i32, i32, C.POINTER(C.c_char_p), C.POINTER(f32p)]
+    L.bert_hip_eval_packed_gather.restype = i32
+    L.bert_hip_eval_packed_gather.argtypes = [vp, i32p, i32p, i32, C.POINTER(vp)]
+    L.bert_hip_reserve.restype = i32; L.bert_hip_reserve.argtypes = [vp, i32, i32]
+    L.bert_hip_check.restype = i32; L.bert_hip_check.argtypes = [vp]
+    L.bert_hip_tokenize_batch.restype = i32
+    L.bert_hip_tokenize_batch.argtypes = [vp, i32, i32, C.POINTER(C.c_char_p), i32p, i32p]
+    L.bert_hip_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+_test_lib = None
+
+
+def test_lib() -> C.CDLL:
+    """libbert_test.so: the product's objects plus the op-level test hooks of include/bert_hip_test.h."""
+    global _test_lib
+    if _test_lib is not None:
+        return _test_lib
+    if not os.path.exists(TEST_LIB_PATH):
+        raise RuntimeError(f"{TEST_LIB_PATH} not found: build it first (make -C bert.cpp_amd)")
+    L = C.CDLL(TEST_LIB_PATH)
+    vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
     L.bert_hip_test_proj_ln.restype = i32
@@ -83,11 +115,38 @@ def lib() -> C.CDLL:
     L.bert_hip_test_qkv_attention.argtypes = [i32, i32p, i32, i32, vp, vp, i32, vp, i32, vp]
     L.bert_hip_test_layer_tail.restype = i32
     L.bert_hip_test_layer_tail.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
-    L.bert_hip_tokenize_batch.restype = i32
-    L.bert_hip_tokenize_batch.argtypes = [vp, i32, i32, C.POINTER(C.c_char_p), i32p, i32p]
-    L.bert_hip_version.restype = C.c_char_p
-    _lib = L
+    L.bert_hip_test_shard_bounds.restype = None
+    L.bert_hip_test_shard_bounds.argtypes = [i32p, i32, i32, i32p]
+    L.bert_hip_test_build_windows.restype = i32
+    L.bert_hip_test_build_windows.argtypes = [i32p, i32, i32p]
+    L.bert_hip_test_dispatch.restype = i32
+    L.bert_hip_test_dispatch.argtypes = [i32p, i32p, i32, i32, i32, C.POINTER(C.c_float)]
+    _test_lib = L
     return L
+
+
+def shard_bounds(cu_seqlens: np.ndarray, n_shards: int) -> List[int]:
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    out = np.zeros(n_shards + 1, dtype=np.int32)
+    test_lib().bert_hip_test_shard_bounds(_i32p(cu), len(cu) - 1, n_shards, _i32p(out))
+    return out.tolist()
+
+
+def build_windows(cu_seqlens: np.ndarray) -> List[tuple]:
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    out = np.zeros(2 * max(len(cu) - 1, 1), dtype=np.int32)
+    n = test_lib().bert_hip_test_build_windows(_i32p(cu), len(cu) - 1, _i32p(out))
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+def dispatch_stub(tokens: np.ndarray, cu_seqlens: np.ndarray, n_shards: int, H: int = 4) -> np.ndarray:
+    tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+    cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    out = np.full((len(cu) - 1, H), np.nan, dtype=np.float32)
+    r = test_lib().bert_hip_test_dispatch(_i32p(tokens), _i32p(cu), len(cu) - 1, n_shards, H, _f32p(out))
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_dispatch failed: {r}")
+    return out
 
 
 def _f32p(a: np.ndarray):
@@ -185,6 +244,34 @@ class BertModel:
             raise RuntimeError(f"bert_hip_eval_packed failed: {r}")
         return out
 
+    def n_devices(self) -> int:
+        return self.lib.bert_hip_n_devices(self.ctx)
+
+    def eval_packed_gather(self, tokens: np.ndarray, cu_seqlens: np.ndarray) -> List[int]:
+        """Evaluates on all devices of the context and gathers on every device: returns the device pointers of the
+        [n_sentences][n_embd] f32 matrices, one per device (owned by the context)."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+        ptrs = (C.c_void_p * self.n_devices())()
+        r = self.lib.bert_hip_eval_packed_gather(self.ctx, _i32p(tokens), _i32p(cu), len(cu) - 1, ptrs)
+        if r != 0:
+            raise RuntimeError(f"bert_hip_eval_packed_gather failed: {r}")
+        return [int(p) for p in ptrs]
+
+    def reserve(self, n_tokens: int, n_sentences: int) -> None:
+        if self.lib.bert_hip_reserve(self.ctx, n_tokens, n_sentences) != 0:
+            raise RuntimeError("bert_hip_reserve failed")
+
+    def check(self) -> int:
+        return self.lib.bert_hip_check(self.ctx)
+
+    def encode_batch_count(self, texts: Sequence[str], n_threads: int = 6):
+        n = len(texts)
+        out = np.full((n, self.n_embd), np.nan, dtype=np.float32)
+        out_ptrs = (C.POINTER(C.c_float) * n)(*[_f32p(out[i]) for i in range(n)])
+        txt = (C.c_char_p * n)(*[t.encode("utf-8") for t in texts])
+        return self.lib.bert_hip_encode_batch(self.ctx, n_threads, n, txt, out_ptrs), out
+
     def eval_packed_device(self, d_tokens_ptr: int, d_cu_ptr: int, n_sentences: int, n_tokens: int, max_len: int,
                            d_out_ptr: int, stream: int = 0) -> None:
         r = self.lib.bert_hip_eval_packed_device(self.ctx, d_tokens_ptr, d_cu_ptr, n_sentences, n_tokens, max_len,
@@ -220,7 +307,7 @@ class BertModel:
 def test_gemm(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias: np.ndarray,
               resid: Optional[np.ndarray], epilogue: int, impl: int) -> np.ndarray:
     """A: float16 [M, K]; W_bytes: file-layout bytes of W[N][K]; returns float16 [M, N]."""
-    L = lib()
+    L = test_lib()
     A = np.ascontiguousarray(A, dtype=np.float16)
     M, K = A.shape
     Wb = np.ascontiguousarray(W_bytes)
@@ -238,7 +325,7 @@ def test_gemm(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias: np.n
 
 
 def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head: int, impl: int) -> np.ndarray:
-    L = lib()
+    L = test_lib()
     qkv = np.ascontiguousarray(qkv, dtype=np.float16)
     cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
     T = qkv.shape[0]
@@ -252,7 +339,7 @@ def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head:
 def test_qkv_attention(x: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head: int, W_bytes: np.ndarray, wtype: int,
                        bias: np.ndarray, fused: bool) -> np.ndarray:
     """x [T][H] f16, Wqkv [3H][H] in file layout of wtype, bias [3H] -> attention context [T][H] f16."""
-    L = lib()
+    L = test_lib()
     x = np.ascontiguousarray(x, dtype=np.float16)
     cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
     w = np.ascontiguousarray(W_bytes)
@@ -268,7 +355,7 @@ def test_qkv_attention(x: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_hea
 def test_layer_tail(ctx: np.ndarray, x: np.ndarray, Wo_bytes, W1_bytes, W2_bytes, wtype: int, I: int, bo, g1, be1, b1, b2,
                     g2, be2, impl: int) -> np.ndarray:
     """ctx, x [M][H] f16 -> layer output [M][H] f16 (out-projection + LN + FFN + LN); impl see bert_hip.h."""
-    L = lib()
+    L = test_lib()
     ctx = np.ascontiguousarray(ctx, dtype=np.float16)
     x = np.ascontiguousarray(x, dtype=np.float16)
     M, H = ctx.shape
@@ -285,7 +372,7 @@ def test_layer_tail(ctx: np.ndarray, x: np.ndarray, Wo_bytes, W1_bytes, W2_bytes
 
 def test_ffn(y: np.ndarray, W1_bytes: np.ndarray, W2_bytes: np.ndarray, wtype: int, I: int, b1, b2, gamma, beta,
              fused: bool) -> np.ndarray:
-    L = lib()
+    L = test_lib()
     y = np.ascontiguousarray(y, dtype=np.float16)
     M, H = y.shape
     w1 = np.ascontiguousarray(W1_bytes); w2 = np.ascontiguousarray(W2_bytes)
@@ -300,7 +387,7 @@ def test_ffn(y: np.ndarray, W1_bytes: np.ndarray, W2_bytes: np.ndarray, wtype: i
 
 
 def test_proj_ln(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias, resid, gamma, beta, fused: bool) -> np.ndarray:
-    L = lib()
+    L = test_lib()
     A = np.ascontiguousarray(A, dtype=np.float16)
     M, K = A.shape
     wb = np.ascontiguousarray(W_bytes)

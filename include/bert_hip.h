@@ -30,7 +30,13 @@ BERT_API int32_t bert_hip_n_head(struct bert_ctx *ctx);
 BERT_API int32_t bert_hip_n_intermediate(struct bert_ctx *ctx);
 BERT_API int32_t bert_hip_n_vocab(struct bert_ctx *ctx);
 BERT_API int32_t bert_hip_ftype(struct bert_ctx *ctx);        /* 0 f32, 1 f16, 2 q4_0, 3 q4_1 */
-BERT_API int32_t bert_hip_device(struct bert_ctx *ctx);       /* HIP device ordinal, -1 if none */
+BERT_API int32_t bert_hip_device(struct bert_ctx *ctx);       /* HIP ordinal of the context's first device, -1 if none */
+BERT_API int32_t bert_hip_n_devices(struct bert_ctx *ctx);    /* GPUs the context spreads its batches over */
+
+/* bert_encode_batch with a result: the number of inputs encoded (all of them, or the inputs in front of the first one
+ * that could not be evaluated — later embeddings stay untouched), negative on an internal error.                     */
+BERT_API int32_t bert_hip_encode_batch(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
+                                       float **embeddings);
 
 /* Packed, variable-length batch evaluation — the engine's native entry point; bert_eval_batch
  * (reference bert.cpp:730-941) is a wrapper that packs the per-sentence host pointers.
@@ -41,13 +47,34 @@ BERT_API int32_t bert_hip_device(struct bert_ctx *ctx);       /* HIP device ordi
 BERT_API int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens,
                                       const int32_t *cu_seqlens, int32_t n_sentences, float *embeddings);
 
-/* Same computation with every buffer already resident in HBM on the context's device; work is
+/* Multi-GPU contexts (BERT_HIP_DEVICES, default: every visible device): bert_eval_batch / bert_encode_batch /
+ * bert_hip_eval_packed cut a call into contiguous shards with near-equal token counts, one per device (weights are
+ * replicated, each device has its own host thread and stream), and every shard writes its embeddings straight into
+ * the caller's host rows.  bert_hip_eval_packed_gather keeps the results on the devices instead and runs the path's one
+ * exchange step — an RCCL all-gather over xGMI (librccl.so is loaded on first use) — so that afterwards EVERY device
+ * holds the whole [n_sentences][n_embd] f32 matrix: d_embeddings[d] receives the pointer on device d (owned by the
+ * context, valid until the next call; bert_hip_n_devices entries).  Blocking.  Per-sentence results are the same bits
+ * whatever the number of devices.  Returns 0, negative on error.                                                      */
+BERT_API int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *tokens, const int32_t *cu_seqlens,
+                                             int32_t n_sentences, float **d_embeddings);
+
+/* Same computation with every buffer already resident in HBM on the context's FIRST device; work is
  * enqueued on `stream` and NOT synchronised (the caller owns the stream).  `max_len` must be >=
- * the longest sentence (it selects the attention kernel variant); n_tokens_total = cu[n].       */
+ * the longest sentence (it selects and sizes the attention kernels); n_tokens_total = cu[n].
+ * Rules of the asynchronous entry point:
+ *   - a context has ONE workspace: a forward pass waits (on its own stream, hipStreamWaitEvent) for the previous pass
+ *     of the context, whatever stream that ran on — passes never overlap, callers need no extra ordering;
+ *   - the workspace grows on demand, and growing allocates (synchronises the device, illegal under stream capture):
+ *     call bert_hip_reserve once with the largest batch first;
+ *   - lengths are validated on the device: a sentence longer than max_len (or empty) yields a NaN embedding and sets a
+ *     status word that bert_hip_check returns (and clears) after synchronising.                                      */
 BERT_API int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens,
                                              const int32_t *d_cu_seqlens, int32_t n_sentences,
                                              int32_t n_tokens_total, int32_t max_len,
                                              float *d_embeddings, void *stream);
+
+BERT_API int32_t bert_hip_reserve(struct bert_ctx *ctx, int32_t n_tokens, int32_t n_sentences);
+BERT_API int32_t bert_hip_check(struct bert_ctx *ctx);        /* 0 ok, 1 a batch broke its max_len promise, < 0 error */
 
 /* Hidden-state tap for parity tests: one sentence, writes hidden[(n_layer+1)][n_tokens][n_embd]
  * f32 (after the embedding LayerNorm and after every encoder layer, reference bert.cpp:806-901)
@@ -64,64 +91,18 @@ BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
 BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
 
 /* Engine knobs (also settable through the environment before bert_load_from_file):
- *   BERT_HIP_DEVICE        device ordinal (default: current device)
+ *   BERT_HIP_DEVICES       "all" (default) or a comma-separated list of HIP ordinals: the GPUs of the context
+ *   BERT_HIP_DEVICE        one ordinal (older spelling of BERT_HIP_DEVICES=<d>)
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
  *   BERT_HIP_ATTN          "mfma" (default) | "naive"
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
  *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
  *   BERT_HIP_TAIL          1 (default) | 0 — token-owning-waves kernel for out-projection + LN + FFN + LN (f16 weights)
- *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernel for batches of long sentences
+ *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernels (sentences of up to 128 tokens)
+ *   BERT_HIP_QKV2          1 (default) | 0 — their second generation (windows of whole sentences, qkv_attention2.hip)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize                            */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
-
-/* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
- * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
- * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
- * 2 bias+residual.  impl: 0 tiled MFMA kernel, 1 naive, 2 row-panel kernel (epilogue 0 only; -2 if the
- * shape is not supported).  Output f16 bits.  Returns 0 on success.                             */
-BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
-                                    int32_t wtype, const float *bias, const uint16_t *resid,
-                                    int32_t epilogue, int32_t impl, uint16_t *C);
-
-/* out = LayerNorm(A W^T + bias + resid) * gamma + beta (reference bert.cpp:859-875).  fused: 1 = single
- * row-panel kernel (-2 if unsupported), 0 = GEMM + LayerNorm kernels.                            */
-BERT_API int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype,
-                                       const float *bias, const uint16_t *resid, const float *gamma,
-                                       const float *beta, int32_t fused, uint16_t *out);
-
-/* Whole feed-forward block: out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * gamma + beta, y [M][H] f16 bits,
- * W1 [I][H] and W2 [H][I] in file layout of `wtype`.  fused: 1 = single fused kernel (returns -2 if the
- * shape is not supported by it), 0 = the three-kernel path (GEMM+GELU, GEMM+residual, LayerNorm).   */
-BERT_API int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2,
-                                   int32_t wtype, const float *b1, const float *b2, const float *gamma,
-                                   const float *beta, int32_t fused, uint16_t *out);
-
-/* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
-BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
-                                         int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);
-
-/* Q|K|V projection + attention: x[T][H] f16 bits, Wqkv [3H][H] (Q rows, K rows, V rows) in file layout of `wtype`,
- * bias[3H] -> ctx[T][H] f16 bits (reference bert.cpp:822-856).  fused: 1 = one kernel per sentence
- * (qkv_attention.hip; -2 if the shape is not supported), 0 = GEMM kernel + attention kernel.       */
-BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
-                                             int32_t d_head, const uint16_t *x, const void *Wqkv, int32_t wtype,
-                                             const float *bias, int32_t fused, uint16_t *out);
-
-/* Everything of a layer after the attention (reference bert.cpp:859-901):
- *   y = LayerNorm(ctx Wo^T + bo + x) * g1 + be1;  out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2
- * ctx, x, out [M][H] f16 bits; Wo [H][H], W1 [I][H], W2 [H][I] in file layout of `wtype`.
- * impl: 0 = GEMM + LayerNorm kernels, 1 = token-owning-waves kernel (layer_tail.hip), 2 = panel kernel
- * (ffn_fused.hip with the leading projection phase); -2 if the shape is not supported by the chosen kernel.   */
-BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x,
-                                          const void *Wo, const void *W1, const void *W2, int32_t wtype,
-                                          const float *bo, const float *g1, const float *be1, const float *b1,
-                                          const float *b2, const float *g2, const float *be2, int32_t impl,
-                                          uint16_t *out);
-
-/* Average milliseconds of `iters` launches of the fused feed-forward kernel on device-resident random data
- * (tuning helper of tools/bench_ffn.py; negative on error).                                              */
-BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters);
 
 BERT_API const char *bert_hip_version(void);
 

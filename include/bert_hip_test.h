@@ -1,0 +1,76 @@
+/* bert_hip_test.h — op-level test hooks of the MI355X engine: standalone kernel entry points (host buffers in, host
+ * buffers out) that the parity tests call through ctypes.  They live in libbert_test.so (libbert.so plus these), NOT in
+ * the product library.
+ */
+#ifndef BERT_HIP_TEST_H
+#define BERT_HIP_TEST_H
+
+#include "bert_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
+ * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
+ * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
+ * 2 bias+residual.  impl: 0 tiled MFMA kernel, 1 naive, 2 row-panel kernel (epilogue 0 only; -2 if the
+ * shape is not supported).  Output f16 bits.  Returns 0 on success.                             */
+BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
+                                    int32_t wtype, const float *bias, const uint16_t *resid,
+                                    int32_t epilogue, int32_t impl, uint16_t *C);
+
+/* out = LayerNorm(A W^T + bias + resid) * gamma + beta (reference bert.cpp:859-875).  fused: 1 = single
+ * row-panel kernel (-2 if unsupported), 0 = GEMM + LayerNorm kernels.                            */
+BERT_API int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype,
+                                       const float *bias, const uint16_t *resid, const float *gamma,
+                                       const float *beta, int32_t fused, uint16_t *out);
+
+/* Whole feed-forward block: out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * gamma + beta, y [M][H] f16 bits,
+ * W1 [I][H] and W2 [H][I] in file layout of `wtype`.  fused: 1 = single fused kernel (returns -2 if the
+ * shape is not supported by it), 0 = the three-kernel path (GEMM+GELU, GEMM+residual, LayerNorm).   */
+BERT_API int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2,
+                                   int32_t wtype, const float *b1, const float *b2, const float *gamma,
+                                   const float *beta, int32_t fused, uint16_t *out);
+
+/* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
+BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
+                                         int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);
+
+/* Q|K|V projection + attention: x[T][H] f16 bits, Wqkv [3H][H] (Q rows, K rows, V rows) in file layout of `wtype`,
+ * bias[3H] -> ctx[T][H] f16 bits (reference bert.cpp:822-856).  fused: 1 = one kernel per sentence
+ * (qkv_attention.hip; -2 if the shape is not supported), 0 = GEMM kernel + attention kernel.       */
+BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
+                                             int32_t d_head, const uint16_t *x, const void *Wqkv, int32_t wtype,
+                                             const float *bias, int32_t fused, uint16_t *out);
+
+/* Everything of a layer after the attention (reference bert.cpp:859-901):
+ *   y = LayerNorm(ctx Wo^T + bo + x) * g1 + be1;  out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2
+ * ctx, x, out [M][H] f16 bits; Wo [H][H], W1 [I][H], W2 [H][I] in file layout of `wtype`.
+ * impl: 0 = GEMM + LayerNorm kernels, 1 = token-owning-waves kernel (layer_tail.hip), 2 = panel kernel
+ * (ffn_fused.hip with the leading projection phase); -2 if the shape is not supported by the chosen kernel.   */
+BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x,
+                                          const void *Wo, const void *W1, const void *W2, int32_t wtype,
+                                          const float *bo, const float *g1, const float *be1, const float *b1,
+                                          const float *b2, const float *g2, const float *be2, int32_t impl,
+                                          uint16_t *out);
+
+/* Average milliseconds of `iters` launches of the fused feed-forward kernel on device-resident random data
+ * (tuning helper of tools/bench_ffn.py; negative on error).                                              */
+BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters);
+
+/* Host logic of the multi-GPU layer and of the sentence windows, callable without a GPU:
+ * shard bounds [n_shards + 1] of a packed batch (multi_device.h), and the {first, count} windows of 128 token slots
+ * (engine.h build_windows; returns their number, `windows` holds 2 ints per window, capacity n_sentences).        */
+BERT_API void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards, int32_t *bounds);
+BERT_API int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows);
+/* The multi-device dispatcher (shard, one thread per shard, results straight into the caller's rows) driven with a stub
+ * evaluator instead of GPUs: row b of `out` [n_sentences][H] becomes f(sentence b) = {sum of ids, length, shard, ...}.  */
+BERT_API int32_t bert_hip_test_dispatch(const bert_vocab_id *tokens, const int32_t *cu_seqlens, int32_t n_sentences,
+                                        int32_t n_shards, int32_t H, float *out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* BERT_HIP_TEST_H */

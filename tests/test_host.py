@@ -40,11 +40,20 @@ def test_library_exports_every_declared_symbol():
     for sym in libbert.BERT_H_SYMBOLS + libbert.BERT_HIP_H_SYMBOLS:
         assert hasattr(L, sym), sym
     # and the headers declare exactly these
-    for hdr, syms in (("bert.h", libbert.BERT_H_SYMBOLS), ("bert_hip.h", libbert.BERT_HIP_H_SYMBOLS)):
+    T = libbert.test_lib()
+    for sym in libbert.BERT_HIP_TEST_H_SYMBOLS:
+        assert hasattr(T, sym), sym
+        assert not hasattr(L, sym), f"{sym} must not ship in the product library"
+    for hdr, syms in (("bert.h", libbert.BERT_H_SYMBOLS), ("bert_hip.h", libbert.BERT_HIP_H_SYMBOLS),
+                      ("bert_hip_test.h", libbert.BERT_HIP_TEST_H_SYMBOLS)):
         text = open(os.path.join(ROOT, "include", hdr)).read()
         declared = set(re.findall(r"BERT_API[^;(]*?\b(bert_\w+)\s*\(", text))
         assert declared == set(syms), (hdr, declared ^ set(syms))
     assert b"gfx950" in L.bert_hip_version()
+    # nm -D of the product library shows no test hook
+    import subprocess
+    names = subprocess.run(["nm", "-D", "--defined-only", libbert.LIB_PATH], capture_output=True, text=True).stdout
+    assert "_test_" not in names and "bench_ffn" not in names
 
 
 def test_tokenizer_reference_known_answers(sparse_vocab_model, tok_golden):

@@ -1,0 +1,202 @@
+"""Host logic of the multi-GPU layer inside libbert.so (csrc/multi_device.cpp) and of the sentence windows of the fused
+projection+attention kernel, through the test library — no GPU needed; and, on the GPU box (-m gpu), the same code with
+real devices: sharded evaluation and the RCCL gather must give the bits of the single-device call."""
+import numpy as np
+import pytest
+
+from bert_cpp_amd import dist as bdist
+from bert_cpp_amd import ggml_file as gf
+from bert_cpp_amd import pybert
+
+
+def _cu(lens):
+    return np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+
+
+def test_shard_bounds_match_the_python_layer_and_balance_tokens():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 4, 8):
+        for n in (1, 2, 7, 100, 1000):
+            lens = rng.integers(1, 513, size=n).tolist()
+            got = pybert.shard_bounds(_cu(lens), world)
+            want = bdist.shard_bounds(lens, world)
+            assert got == [want[0][0]] + [e for _, e in want], (world, n)
+            assert got[0] == 0 and got[-1] == n and all(a <= b for a, b in zip(got, got[1:]))
+            if n >= 4 * world:
+                tok = [sum(lens[a:b]) for a, b in zip(got, got[1:])]
+                assert max(tok) - min(tok) <= 2 * 512
+    assert pybert.shard_bounds(_cu([128] * 1024), 8) == [i * 128 for i in range(9)]
+    # a window of a larger batch (prefix sums not starting at 0): the dispatcher passes cu + first
+    cu = _cu([5, 9, 100, 3, 64, 64, 7])
+    assert pybert.shard_bounds(cu[2:], 2) == [b - 0 for b in pybert.shard_bounds(_cu([100, 3, 64, 64, 7]), 2)]
+
+
+def test_windows_hold_whole_sentences_in_order_and_fit():
+    rng = np.random.default_rng(1)
+    for trial in range(50):
+        n = int(rng.integers(1, 300))
+        lens = np.clip(np.round(rng.lognormal(np.log(21.0), 0.7, n)), 1, 128).astype(int).tolist()
+        win = pybert.build_windows(_cu(lens))
+        assert win[0][0] == 0 and sum(c for _, c in win) == n
+        nxt = 0
+        for first, count in win:
+            assert first == nxt and count >= 1
+            nxt = first + count
+            fill = 0
+            for L in lens[first:first + count]:
+                assert fill + L <= 128                     # the sentence starts at a multiple of 16 and fits
+                fill = (fill + L + 15) // 16 * 16
+        # next-fit: a window is only closed when the next sentence does not fit
+        for (f0, c0), (f1, _) in zip(win, win[1:]):
+            fill = 0
+            for L in lens[f0:f0 + c0]:
+                fill = (fill + L + 15) // 16 * 16
+            assert fill + lens[f1] > 128
+    assert pybert.build_windows(_cu([128] * 5)) == [(i, 1) for i in range(5)]
+    assert pybert.build_windows(_cu([16] * 8 + [1])) == [(0, 8), (8, 1)]
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
+def test_dispatcher_with_a_stub_evaluator(n_shards):
+    """The code path of a multi-GPU bert_eval_batch (shard, one thread per shard, every shard writes the caller's rows)
+    with a stub in place of the engines: every sentence is evaluated exactly once, by the shard that owns it."""
+    rng = np.random.default_rng(n_shards)
+    for n in (1, 2, 5, 64, 500):
+        lens = rng.integers(1, 200, size=n)
+        cu = _cu(lens)
+        toks = rng.integers(0, 30000, size=int(cu[-1])).astype(np.int32)
+        out = pybert.dispatch_stub(toks, cu, n_shards, H=4)
+        bounds = pybert.shard_bounds(cu, n_shards)
+        for b in range(n):
+            shard = max(r for r in range(n_shards) if bounds[r] <= b and b < bounds[r + 1])
+            want = [float(np.float32(toks[cu[b]:cu[b + 1]].astype(np.int64).sum())), float(lens[b]), float(shard), float(b)]
+            assert out[b].tolist() == want, (n, b)
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+class _Hip:
+    """Just enough of the HIP runtime through ctypes (the runtime libbert.so itself is linked against)."""
+
+    def __init__(self):
+        import ctypes as C
+        self.C = C
+        self.lib = C.CDLL("libamdhip64.so")
+
+    def malloc(self, nbytes):
+        p = self.C.c_void_p()
+        assert self.lib.hipMalloc(self.C.byref(p), self.C.c_size_t(nbytes)) == 0
+        return p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.malloc(arr.nbytes)
+        assert self.lib.hipMemcpy(self.C.c_void_p(p), self.C.c_void_p(arr.ctypes.data), self.C.c_size_t(arr.nbytes), 1) == 0
+        return p
+
+    def download(self, p, shape, dtype=np.float32, device=None):
+        if device is not None:
+            assert self.lib.hipSetDevice(device) == 0
+        out = np.empty(shape, dtype=dtype)
+        assert self.lib.hipDeviceSynchronize() == 0
+        assert self.lib.hipMemcpy(self.C.c_void_p(out.ctypes.data), self.C.c_void_p(p), self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def stream(self):
+        s = self.C.c_void_p()
+        assert self.lib.hipStreamCreate(self.C.byref(s)) == 0
+        return s.value
+
+
+@pytest.mark.gpu
+def test_gather_entry_point_matches_the_host_api(make_model, monkeypatch):
+    """bert_hip_eval_packed_gather on the devices of this box (one on the test box): the device-resident matrix equals the
+    host API's result bit for bit; with BERT_HIP_RCCL_SINGLE=1 the exchange runs through a 1-rank RCCL communicator."""
+    hip = _Hip()
+    path, hp = make_model("minilm-l6", "f16", 0)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(1, 129, size=300)
+    cu = _cu(lens)
+    toks = rng.integers(1000, hp.n_vocab, size=int(cu[-1])).astype(np.int32)
+    m = pybert.BertModel(path)
+    want = m.eval_packed(toks, cu)
+    for force in ("0", "1"):
+        monkeypatch.setenv("BERT_HIP_RCCL_SINGLE", force)
+        ptrs = m.eval_packed_gather(toks, cu)
+        assert len(ptrs) == m.n_devices() >= 1
+        for d, p in enumerate(ptrs):
+            assert np.array_equal(hip.download(p, (len(lens), hp.n_embd), device=d), want), (force, d)
+
+
+@pytest.mark.gpu
+def test_device_api_guards(make_model, capfd):
+    """bert_hip_eval_packed_device trusts max_len for kernel selection; a batch that breaks the promise must not produce
+    silent garbage: NaN rows for the offending sentences and bert_hip_check() == 1."""
+    hip = _Hip()
+    path, hp = make_model("minilm-l6", "f16", 0)
+    m = pybert.BertModel(path)
+    lens = [20, 100, 64, 7]
+    cu = _cu(lens)
+    T, H = int(cu[-1]), hp.n_embd
+    toks = np.random.default_rng(0).integers(1000, hp.n_vocab, size=T).astype(np.int32)
+    want = m.eval_packed(toks, cu)
+    d_t, d_cu = hip.upload(toks), hip.upload(cu)
+    out = hip.upload(np.full((4, H), 7.0, np.float32))
+    m.reserve(T, 4)
+    m.eval_packed_device(d_t, d_cu, 4, T, 128, out, 0)
+    assert m.check() == 0
+    assert np.array_equal(hip.download(out, (4, H)), want)
+    # promise 64, deliver 100: sentence 1 is flagged, the others are unaffected
+    m.eval_packed_device(d_t, d_cu, 4, T, 64, out, 0)
+    assert m.check() == 1 and m.check() == 0
+    got = hip.download(out, (4, H))
+    assert np.isnan(got[1]).all() and np.array_equal(got[[0, 2, 3]], want[[0, 2, 3]])
+    assert "max_len" in capfd.readouterr().err
+    # a max_len that cannot hold the tokens at all is refused on the host
+    with pytest.raises(RuntimeError):
+        m.eval_packed_device(d_t, d_cu, 4, T, 16, out, 0)
+    # two streams, back to back: the context serialises its passes itself
+    s1, s2 = hip.stream(), hip.stream()
+    o1, o2 = hip.malloc(4 * H * 4), hip.malloc(4 * H * 4)
+    for _ in range(5):
+        m.eval_packed_device(d_t, d_cu, 4, T, 128, o1, s1)
+        m.eval_packed_device(d_t, d_cu, 4, T, 128, o2, s2)
+    assert np.array_equal(hip.download(o1, (4, H)), want) and np.array_equal(hip.download(o2, (4, H)), want)
+
+
+@pytest.mark.gpu
+def test_no_exception_crosses_the_abi(make_model, capfd, monkeypatch):
+    path, hp = make_model("tiny", "f16", 1)
+    m = pybert.BertModel(path)
+    s = np.arange(5, dtype=np.int32)
+    monkeypatch.setenv("BERT_HIP_INJECT_BAD_ALLOC", "1")
+    out = m.eval_batch([s, s])
+    assert np.isnan(out).all()                              # outputs untouched, the process is alive
+    assert "bert_eval_batch: std::bad_alloc" in capfd.readouterr().err
+    n, out = m.encode_batch_count(["a b", "c"])
+    assert n == -1 or n == 0
+    assert np.isnan(out).all()
+    monkeypatch.delenv("BERT_HIP_INJECT_BAD_ALLOC")
+    assert np.isfinite(m.eval_batch([s])).all()
+
+
+@pytest.mark.gpu
+def test_gemm_option_toggled_after_load(make_model, capfd, monkeypatch):
+    """set_option("gemm", "naive") after a default load used to make the generic kernel read a null image: it
+    is refused now unless the images were built at load time; with them both families agree."""
+    path, hp = make_model("tiny-h128", "f16", 1)
+    s = [np.random.default_rng(0).integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (9, 40, 64)]
+    m = pybert.BertModel(path)
+    base = m.eval_batch(s)
+    m.set_option("gemm", "naive")
+    assert "ignored" in capfd.readouterr().err
+    assert np.array_equal(m.eval_batch(s), base)
+    monkeypatch.setenv("BERT_HIP_GEMM", "naive")
+    m2 = pybert.BertModel(path)
+    monkeypatch.delenv("BERT_HIP_GEMM")
+    naive = m2.eval_batch(s)
+    m2.set_option("gemm", "mfma")
+    fast = m2.eval_batch(s)
+    m2.set_option("gemm", "naive")
+    assert np.array_equal(m2.eval_batch(s), naive)
+    for a, b in zip(naive, fast):
+        assert float(a @ b) > 1 - 1e-5
