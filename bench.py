@@ -3,21 +3,31 @@
 
 A "step" is one pass of the hot path (bert_hip_eval_packed_device: embeddings -> L encoder
 layers -> mean-pool + L2) over one batch of synthetic token ids that is already resident in HBM;
-with --gpus N > 1 each rank evaluates its own shard of sentences (weights replicated, no data-path
-collective inside the forward pass) and the step ends with ONE RCCL all-gather of the final
-embeddings over xGMI, as BASELINE.json's north_star describes.  value = sentences all ranks
-processed / max-over-ranks wall time.
+with --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) each rank evaluates its own
+shard of sentences (weights replicated, no data-path collective inside the forward pass) and the step
+ends with ONE RCCL all-gather of the final embeddings over xGMI, as BASELINE.json's north_star
+describes.  value = sentences all ranks processed / max-over-ranks wall time.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --inproc          # ONE process, N GPUs inside libbert.so (BERT_HIP_DEVICES, RCCL gather)
 
-Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task description).  The timed region of K steps is
+repeated (--repeat, default 5): `value` / `ms_per_step` are the MEDIAN region, `regions` lists them all
+(the boxes of the pool and the chip's power management spread single regions by several percent).
+Extra objects:
   roofline     — dominant kernel, algorithmic FLOPs per launch / HIP-event launch duration vs the
-                 dense f16 MFMA peak (2.5 PFLOP/s);
+                 dense f16 MFMA peak (2.5 PFLOP/s); traffic = HBM bytes per launch from the committed
+                 rocprofv3 PMC pass (profiles/traffic.json);
+  host_api     — the same batch through the host-to-host API (bert_hip_eval_packed = what
+                 bert_eval_batch runs after packing its pointer arrays: pinned staging, H2D ids, forward,
+                 D2H embeddings, blocking): SURVEY.md §8(d)'s metric as the reference's callers see it;
   cpu_baseline — the CPU oracle in ggml-faithful mode (kind "port": the reference itself cannot be
                  built, its arithmetic lives in the un-vendored ggml submodule) timed on this box's
-                 host cores over a bounded sample of the same sentences.
+                 host cores over a bounded sample of the same sentences;
+  also         — the other single-GPU BASELINE configs (2 as written and with the engine default, 3) and a
+                 real-text-like mixed-length batch, each with its own roofline / cosine / cpu sample.
 """
 import argparse
 import json
@@ -51,6 +61,11 @@ CONFIGS = {
     3: dict(name="bert-base-uncased q4_1, batch=512 seq_len=512", dims="bert-base", ftype="q4_1", batch=512, seq_len=512),
     4: dict(name="mpnet-base dims (BERT arch) q4_0, seq_len=128, 8192-sentence steps", dims="mpnet-dims", ftype="q4_0",
             batch=8192, seq_len=128),
+    # not a BASELINE config: sentence lengths like real text (reference examples/sample_client_texts.txt: ~22 words per line)
+    # (the step of this one is the HOST API — bert_hip_eval_packed — because only the host path knows the lengths when it
+    # places the sentences into the windows of the fused attention kernel; the device API uses one window per sentence)
+    5: dict(name="all-MiniLM-L6-v2 f16, 16384 sentences of mixed length (log-normal, mean ~25 tokens, 3..128), host API", dims="minilm-l6",
+            ftype="f16", batch=16384, seq_len=None, key="mixed_len", host_step=True),
 }
 
 
@@ -59,69 +74,108 @@ def flops_per_sentence(hp, n):
     return L * (n * (8 * H * H + 4 * H * I) + 4 * n * n * H) + 2 * n * H
 
 
-def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir):
-    cfg = CONFIGS[cfg_id]
-    hp = gf.MODEL_DIMS[cfg["dims"]]
-    path = os.path.join(tmpdir, f"{cfg['dims']}_{cfg['ftype']}_rank{rank}.bin")
-    if not os.path.exists(path):
-        gf.make_synthetic_model(path, cfg["dims"], cfg["ftype"], seed=0)
+def config_inputs(cfg, cfg_id, hp, rank):
+    """(flat ids, cu_seqlens, max_len): seeded synthetic ids of SURVEY.md §8d."""
+    B, N = cfg["batch"], cfg["seq_len"]
+    if N is not None:
+        ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + (cfg_id % 20) + 1000 * rank)
+        return ids.reshape(-1), (np.arange(B + 1) * N).astype(np.int32), N
+    rng = np.random.default_rng(5 + rank)
+    lens = np.clip(np.round(rng.lognormal(np.log(21.0), 0.55, B)), 3, 128).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = rng.integers(1000, hp.n_vocab, size=int(cu[-1])).astype(np.int32)
+    ids[cu[:-1]] = 101
+    ids[cu[1:] - 1] = 102
+    return ids, cu, int(lens.max())
+
+
+def load_model(cfg, path):
     saved = {k: os.environ.get(k) for k in cfg.get("env", {})}
     os.environ.update(cfg.get("env", {}))                 # engine options are read when the model is loaded
     try:
-        model = pybert.BertModel(path)
+        return pybert.BertModel(path)
     finally:
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    B, N, H = cfg["batch"], cfg["seq_len"], hp.n_embd
-    ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + (cfg_id % 20) + 1000 * rank)
-    d_tokens = torch.from_numpy(ids.reshape(-1)).to(device)
-    d_cu = torch.arange(0, (B + 1) * N, N, dtype=torch.int32, device=device)
+
+
+def timed_regions(step, steps, warmup, repeat, sync, barrier=None, reduce_max=None):
+    """W untimed steps, then `repeat` regions of exactly `steps` steps, each bracketed by barrier + synchronize on both
+    sides; per region the max over ranks.  Returns the list of region times (s)."""
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(repeat):
+        sync()
+        if barrier:
+            barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        if barrier:
+            barrier()
+        sync()
+        dt = time.perf_counter() - t0
+        out.append(reduce_max(dt) if reduce_max else dt)
+    return out
+
+
+def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=None, warmup=None, repeat=None):
+    cfg = CONFIGS[cfg_id]
+    hp = gf.MODEL_DIMS[cfg["dims"]]
+    path = os.path.join(tmpdir, f"{cfg['dims']}_{cfg['ftype']}_rank{rank}.bin")
+    if not os.path.exists(path):
+        gf.make_synthetic_model(path, cfg["dims"], cfg["ftype"], seed=0)
+    model = load_model(cfg, path)
+    B, H = cfg["batch"], hp.n_embd
+    flat, cu, max_len = config_inputs(cfg, cfg_id, hp, rank)
+    T = int(cu[-1])
+    d_tokens = torch.from_numpy(flat).to(device)
+    d_cu = torch.from_numpy(cu).to(device)
     d_out = torch.empty((B, H), dtype=torch.float32, device=device)
     stream = torch.cuda.current_stream(device)
     counts = [B] * world
     d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
+    model.reserve(T, B)
 
     def step():
-        model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, B * N, N, d_out.data_ptr(), stream.cuda_stream)
+        if cfg.get("host_step"):
+            d_out.copy_(torch.from_numpy(model.eval_packed(flat, cu)))
+            return
+        model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_out.data_ptr(), stream.cuda_stream)
         if world > 1:
             # RCCL over xGMI: the path's one exchange step (bert.cpp_amd/dist.py), [world*B, H] on every rank
             bdist.gather_embeddings(d_out, counts, out=d_all)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    dt = time.perf_counter() - t0
-    if world > 1:
+    def reduce_max(dt):
+        if world == 1:
+            return dt
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    sent_per_s = world * B * args.steps / dt
-    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, ids=ids, out=d_out, dt=dt, value=sent_per_s,
-               ms_per_step=1e3 * dt / args.steps, step=step)
+        return float(t.item())
+
+    steps = steps or args.steps
+    regions = timed_regions(step, steps, warmup if warmup is not None else args.warmup, repeat or args.repeat,
+                            lambda: torch.cuda.synchronize(device), dist.barrier if world > 1 else None, reduce_max)
+    dt = float(np.median(regions))
+    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=d_out, steps=steps, regions=regions,
+               value=world * B * steps / dt, ms_per_step=1e3 * dt / steps, step=step, tokens=T, max_len=max_len)
     return res
 
 
-def committed_traffic(cfg_id, kernel):
+def committed_traffic(cfg_key, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC pass of this same command
     (profiles/traffic.json, written by tools/pmc_traffic.py: FETCH_SIZE doubled as the gfx950 note of
     MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  Counters cannot be read from inside the process."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        d = t.get(f"config{cfg_id}", {}).get(kernel)
+        d = t.get(cfg_key, {}).get(kernel)
         return None if d is None else d["bytes"]
     except (OSError, ValueError, KeyError):
         return None
@@ -140,61 +194,140 @@ def kernel_roofline(res, torch, device, steps=5):
         return None, rep
     name, st = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
     avg_s = st["total_ms"] / st["launches"] * 1e-3
-    achieved = st["flops_per_launch"] / avg_s if avg_s > 0 else 0.0
+    flops = st["flops_per_launch"]
+    if name.startswith("qkv_attention") and res["cfg"]["seq_len"]:
+        # the engine books attention FLOPs with an upper bound (max_len); exact for equal lengths
+        pass
+    achieved = flops / avg_s if avg_s > 0 else 0.0
     total_ms = sum(v["total_ms"] for v in rep.values())
+    key = res["cfg"].get("key", f"config{res['cfg_id']}")
     roof = {"bound": "mfma", "kernel": name, "achieved": achieved / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_F16, "traffic": committed_traffic(res.get("cfg_id"), name),
-            "avg_launch_us": avg_s * 1e6, "flops_per_launch": st["flops_per_launch"],
+            "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_F16, "traffic": committed_traffic(key, name),
+            "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops,
             "kernel_time_share": st["total_ms"] / total_ms if total_ms else None}
     breakdown = {k: round(v["total_ms"] / steps, 4) for k, v in sorted(rep.items())}
     return roof, breakdown
 
 
-def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096):
+def host_api_rate(res, calls=None):
+    """Host-to-host: ids in host memory -> embeddings in host memory through bert_hip_eval_packed (blocking)."""
+    m, flat, cu = res["model"], res["flat"], res["cu"]
+    B = len(cu) - 1
+    calls = calls or max(3, min(50, int(0.25 / max(res["ms_per_step"] * 1e-3, 1e-4))))
+    for _ in range(2):
+        out = m.eval_packed(flat, cu)
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        m.eval_packed(flat, cu)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": B / med, "unit": "sentences/s", "ms_per_call": 1e3 * med, "min": B / max(ts), "max": B / min(ts), "calls": calls,
+            "entry": "bert_hip_eval_packed (host ids -> host embeddings: pinned staging, H2D, forward, D2H, blocking)"}, out
+
+
+def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None):
     """Oracle (ggml-faithful mode) on the host cores over a bounded sample of the same sentences."""
     from oracle import oracle as orc
 
     o = orc.Oracle(res["path"])
-    # intra-op threading over the sentence's 128 token rows (like ggml's n_threads): more threads
+    # intra-op threading over the sentence's token rows (like ggml's n_threads): more threads
     # than ~32 only add barrier cost, and the box's logical-CPU count can exceed its cgroup quota
     cores = int(os.environ.get("ORACLE_THREADS", min(orc.usable_cores(), 32)))
-    gpu = res["out"].cpu().numpy()
-    ids = res["ids"]
-    o.eval(ids[0], orc.MODE_GGML, cores)            # warm-up (tables, page-in)
+    gpu = res["out"].cpu().numpy() if gpu is None else gpu
+    flat, cu = res["flat"], res["cu"]
+    B = len(cu) - 1
+    sent = lambda i: flat[cu[i]:cu[i + 1]]
+    o.eval(sent(0), orc.MODE_GGML, cores)            # warm-up (tables, page-in)
     n, t0, coss = 0, time.perf_counter(), []
     while n < max_sent and (time.perf_counter() - t0 < budget_s or n < 2):
-        i = n % len(ids)                      # bounded sample: cycle through the step's sentences
-        ref = o.eval(ids[i], orc.MODE_GGML, cores)
-        if n < len(ids):
+        i = n % B                             # bounded sample: cycle through the step's sentences
+        ref = o.eval(sent(i), orc.MODE_GGML, cores)
+        if n < B:
             coss.append(float(gpu[i] @ ref / (np.linalg.norm(gpu[i]) * np.linalg.norm(ref))))
         n += 1
     dt = time.perf_counter() - t0
     base = {"value": n / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
-            "sample": f"{n} single-sentence evaluations drawn from the step's sentences (seq_len {ids.shape[1]}), oracle ggml-faithful mode, "
+            "sample": f"{n} single-sentence evaluations drawn from the step's sentences (mean length {res['tokens'] / B:.0f}), oracle ggml-faithful mode, "
                       f"OpenMP {cores} threads (usable cores {orc.usable_cores()}, logical {os.cpu_count()}), {dt:.1f} s"}
     return base, float(np.mean(coss)), float(np.min(coss)), n
+
+
+def report(res, world, torch, device, args, prof_steps, cpu_budget):
+    cfg, hp = res["cfg"], res["hp"]
+    B = cfg["batch"]
+    fl = [flops_per_sentence(hp, int(n)) for n in np.diff(res["cu"])] if cfg["seq_len"] is None else None
+    fps = float(np.mean(fl)) if fl else flops_per_sentence(hp, cfg["seq_len"])
+    r = sorted(world * B * res["steps"] / np.asarray(res["regions"]))
+    e = {"workload": cfg["name"], "value": res["value"], "unit": "sentences/s", "ms_per_step": res["ms_per_step"],
+         "regions": {"n": len(r), "steps_each": res["steps"], "median": float(np.median(r)), "min": float(r[0]), "max": float(r[-1])},
+         "path_gflop_per_sentence": fps / 1e9, "path_mfma_frac": res["value"] * fps / (world * MFMA_PEAK_F16)}
+    roof, bd = kernel_roofline(res, torch, device, steps=prof_steps)
+    e["roofline"] = roof
+    e["kernel_ms_per_step"] = bd
+    if world == 1:
+        e["host_api"], host_out = host_api_rate(res)
+        if not args.no_cpu_baseline:
+            base, mc, mn, _ = cpu_baseline_and_cosine(res, budget_s=cpu_budget, gpu=host_out)
+            e.update(cpu_baseline=base, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn, speedup_vs_cpu=res["value"] / base["value"])
+    return e
+
+
+def run_inproc(args):
+    """ONE process drives N GPUs through libbert.so's own multi-device layer (BERT_HIP_DEVICES): token-balanced shards, one
+    host thread + stream per device, RCCL all-gather of the embeddings (bert_hip_eval_packed_gather).  Host-resident ids."""
+    n = args.gpus
+    os.environ["BERT_HIP_DEVICES"] = ",".join(str(d) for d in range(n))
+    cfg = CONFIGS[args.config]
+    hp = gf.MODEL_DIMS[cfg["dims"]]
+    with tempfile.TemporaryDirectory(prefix="bert_bench_") as tmpdir:
+        path = os.path.join(tmpdir, "m.bin")
+        gf.make_synthetic_model(path, cfg["dims"], cfg["ftype"], seed=0)
+        m = load_model(cfg, path)
+        ids, cu, _ = config_inputs(dict(cfg, batch=cfg["batch"] * n), args.config, hp, 0)
+        B = len(cu) - 1
+        regions = timed_regions(lambda: m.eval_packed_gather(ids, cu), args.steps, args.warmup, args.repeat, lambda: None)
+        dt = float(np.median(regions))
+        r = sorted(B * args.steps / np.asarray(regions))
+        fps = flops_per_sentence(hp, cfg["seq_len"] or 25)
+        print(json.dumps({
+            "metric": "sentences/sec (seq_len=%s)" % cfg["seq_len"], "value": B * args.steps / dt, "unit": "sentences/s", "n_gpus": m.n_devices(),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic (seeded random weights in bert.cpp file format, random token ids)",
+            "config": {"workload": cfg["name"], "per_gpu_batch": cfg["batch"], "global_batch": B, "seq_len": cfg["seq_len"],
+                       "weights": cfg["ftype"], "parallelism": f"dp{n} inside one process (libbert.so: one engine + thread + stream per device, "
+                                                                "RCCL all-gather of embeddings per step; ids start in HOST memory)"},
+            "regions": {"n": len(r), "steps_each": args.steps, "median": float(np.median(r)), "min": float(r[0]), "max": float(r[-1])},
+            "path_mfma_frac": B * args.steps / dt * fps / (n * MFMA_PEAK_F16)}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--also", type=int, nargs="*", default=None,
-                    help="extra BASELINE configs reported under 'also' (default at N=1: config 2)")
+                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inproc", action="store_true", help="one process, --gpus N devices inside libbert.so")
     args = ap.parse_args()
-
-    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.inproc and world == 1:
+        return run_inproc(args)
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # one rank = one GPU: the rank's context lives on its own device only
+    os.environ["BERT_HIP_DEVICES"] = str(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -207,10 +340,10 @@ def main():
         res = run_config(args.config, args, rank, world, device, dist, torch, tmpdir)
         line = None
         if rank == 0:
-            cfg, hp = res["cfg"], res["hp"]
-            fps = flops_per_sentence(hp, cfg["seq_len"])
+            cfg = res["cfg"]
+            e = report(res, world, torch, device, args, prof_steps=5, cpu_budget=12.0)
             line = {
-                "metric": "sentences/sec (seq_len=%d)" % cfg["seq_len"], "value": res["value"], "unit": "sentences/s",
+                "metric": "sentences/sec (seq_len=%s)" % cfg["seq_len"], "value": res["value"], "unit": "sentences/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
                 "data": "synthetic (seeded random weights in bert.cpp file format, random token ids)",
@@ -218,38 +351,22 @@ def main():
                            "seq_len": cfg["seq_len"], "weights": cfg["ftype"],
                            "parallelism": f"dp{world} (replicated weights, sharded sentences"
                                           + (", RCCL all-gather of embeddings per step)" if world > 1 else ")")},
-                "path_gflop_per_sentence": fps / 1e9,
-                "path_mfma_frac": res["value"] * fps / (world * MFMA_PEAK_F16),
             }
-        roof, breakdown = kernel_roofline(res, torch, device)
-        if rank == 0:
-            line["roofline"] = roof
-            line["kernel_ms_per_step"] = breakdown
-            if world == 1 and not args.no_cpu_baseline:
-                base, mean_cos, min_cos, n = cpu_baseline_and_cosine(res)
-                line["cpu_baseline"] = base
-                line["mean_cosine_vs_cpu"] = mean_cos
-                line["min_cosine_vs_cpu"] = min_cos
-                line["speedup_vs_cpu"] = res["value"] / base["value"]
+            line.update({k: v for k, v in e.items() if k not in ("workload", "value", "unit", "ms_per_step")})
+        else:
+            kernel_roofline(res, torch, device)
         res["model"].close()
-        also = args.also if args.also is not None else ([2, 22] if world == 1 and args.config == 1 else [])
+        also = args.also if args.also is not None else ([2, 22, 3, 5] if world == 1 and args.config == 1 else [])
         extras = {}
         for cid in also:
-            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir)
+            big = CONFIGS[cid]["dims"] in ("bert-base", "mpnet-dims")
+            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir, steps=3 if big else max(10, args.steps // 4),
+                            warmup=1 if big else 5, repeat=3)
             if rank == 0:
-                fps2 = flops_per_sentence(r2["hp"], r2["cfg"]["seq_len"])
-                e = {"workload": r2["cfg"]["name"], "value": r2["value"], "unit": "sentences/s",
-                     "ms_per_step": r2["ms_per_step"], "path_mfma_frac": r2["value"] * fps2 / (world * MFMA_PEAK_F16)}
-                roof2, bd2 = kernel_roofline(r2, torch, device, steps=3)
-                e["roofline"] = roof2
-                e["kernel_ms_per_step"] = bd2
-                if world == 1 and not args.no_cpu_baseline:
-                    base2, mc, mn, _ = cpu_baseline_and_cosine(r2, budget_s=6.0 if cid == 2 else 3.0)
-                    e.update(cpu_baseline=base2, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn,
-                             speedup_vs_cpu=r2["value"] / base2["value"])
-                extras[r2["cfg"].get("key", f"config{cid}")] = e
+                extras[r2["cfg"].get("key", f"config{cid}")] = report(r2, world, torch, device, args, prof_steps=2 if big else 3,
+                                                                       cpu_budget=8.0 if big else 4.0)
             else:
-                kernel_roofline(r2, torch, device, steps=3)
+                kernel_roofline(r2, torch, device, steps=2 if big else 3)
             r2["model"].close()
         if rank == 0:
             if extras:

@@ -35,8 +35,10 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__restrict__ qkv,
+// NT threads: 256 (4 waves), or 512 for long sentences (their K / V^T fill most of the CU's LDS, so one workgroup is all
+// a CU holds: 8 waves = two per SIMD let one wave's softmax run under the other's MFMAs)
+template <int D, int NT>
+__global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__restrict__ qkv,
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,
                                                              half_t *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
 
     // ---- stage K (swizzled rows) and V^T (transposed) of this head; zero the padding
     constexpr int CPR = D / 8;                         // 16-byte chunks per row
-    for (int idx = tid; idx < n_pad * CPR; idx += 256) {
+    for (int idx = tid; idx < n_pad * CPR; idx += NT) {
         const int row = idx / CPR, c = idx % CPR;
         uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
         if (row < n) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(const half_t *__res
     __syncthreads();
 
     const float sc = 1.44269504088896340736f / __builtin_sqrtf((float)D);   // log2(e) / sqrt(d)
-    for (int qb = wave; qb < n_qblocks; qb += 4) {
+    for (int qb = wave; qb < n_qblocks; qb += NT / 64) {
         if (qb != wave) {                              // later blocks (n > 128): fetch their Q fragments now
             const int qrow = min(qb * 32 + l31, n - 1);
             const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
@@ -189,15 +191,18 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
                        hipStream_t s) {
     const int n_pad = (max_len + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const size_t lds = (size_t)n_pad * D * 2 + (size_t)D * (n_pad + VT_PAD) * 2;
-    static size_t configured[MAX_HIP_DEVICES] = {};           // per device: the opt-in is a per-device attribute
+    static size_t configured[2][MAX_HIP_DEVICES] = {};        // per device: the opt-in is a per-device attribute
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev &= MAX_HIP_DEVICES - 1;
-    if (lds > 64 * 1024 && lds > configured[dev]) {
-        (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured[dev] = lds;
+    const bool wide = n_pad > 128;
+    if (lds > 64 * 1024 && lds > configured[wide][dev]) {
+        if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured[wide][dev] = lds;
     }
-    hipLaunchKernelGGL((attention_mfma_kernel<D>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
+    if (wide) hipLaunchKernelGGL((attention_mfma_kernel<D, 512>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
+    else hipLaunchKernelGGL((attention_mfma_kernel<D, 256>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }
 
 bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,

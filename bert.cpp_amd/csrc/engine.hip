@@ -189,6 +189,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV2")) e->qkv2_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_GEMM256")) e->gemm256_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
@@ -251,7 +252,7 @@ Engine::~Engine() {
 bool Engine::reserve(int n_tokens, int n_sentences, std::string &err) {
     HIP_OK(hipSetDevice(device_), err, false);
     if (n_tokens <= 0 || n_sentences <= 0) return true;
-    return ensure_workspace((n_tokens + GEMM_BM - 1) / GEMM_BM * GEMM_BM, n_sentences, err);
+    return ensure_workspace((n_tokens + 255) / 256 * 256, n_sentences, err);
 }
 
 int Engine::check(std::string &err) {
@@ -279,6 +280,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "layer_fused") layer_fused_ = value != "0";
     else if (key == "qkv_att") qkv_att_ = value != "0";
     else if (key == "qkv2") qkv2_ = value != "0";
+    else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
@@ -349,7 +351,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     if (B <= 0 || T <= 0) return 0;
     HIP_OK(hipSetDevice(device_), err, -1);
     const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
-    const int t_pad = (T + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int t_pad = (T + 255) / 256 * 256;                 // whole tiles of every kernel family (128- and 256-token tiles)
     if (!ensure_workspace(t_pad, B, err)) return -1;
     // one forward pass at a time on the shared workspace: wait (on the caller's stream) for the previous pass
     HIP_OK(hipStreamWaitEvent(s, busy_, 0), err, -1);
@@ -360,7 +362,8 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
                     half_t *C, int epi) {
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (W.mfma_ok && (!gemm_naive_ || !W.w.naive16)) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad)) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
+            else if (W.mfma_ok && (!gemm_naive_ || !W.w.naive16)) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
     };
@@ -390,7 +393,8 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                 launch_qkv_attention(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, nh, ctx, s);
             });
         } else {
-        if (panel_ && !gemm_naive_ && L.qkv.mfma_ok && panel_gemm_supported(L.qkv.w, false))
+        if (panel_ && !gemm_naive_ && L.qkv.mfma_ok && panel_gemm_supported(L.qkv.w, false) &&
+            !(gemm256_ && H > 384 && gemm256_supported(L.qkv.w, t_pad)))
             timed("panel_qkv", 2.0 * Td * L.qkv.w.N * L.qkv.w.K, s, [&] { launch_panel_store(L.qkv.w, x, L.qkv_b.as<float>(), qkv, t_pad, s); });
         else
             gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
@@ -483,7 +487,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
             !sl.d_windows.ensure(max_nb * sizeof(int2), err)) return -1;
         if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
     }
-    if (!ensure_workspace((int)((max_T + GEMM_BM - 1) / GEMM_BM * GEMM_BM), (int)max_nb, err)) return -1;
+    if (!ensure_workspace((int)((max_T + 255) / 256 * 256), (int)max_nb, err)) return -1;
 
     // The stream executes H2D, forward, D2H of chunk after chunk; the host runs one chunk ahead: it stages chunk i
     // into slot i & 1 and queues it, then unpacks chunk i-1 while chunk i computes.
@@ -533,7 +537,7 @@ int Engine::eval_hidden(const int32_t *tokens, int N, float *hidden, float *embe
     int32_t cu[2] = {0, N};
     if (!d_tokens_.ensure((size_t)N * 4, err) || !d_cu_.ensure(8, err)) return -1;
     if (!d_hidden_.ensure((size_t)(L + 1) * N * H * 4, err)) return -1;
-    const int t_pad = (N + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int t_pad = (N + 255) / 256 * 256;
     if (!ensure_workspace(t_pad, 1, err)) return -1;
     HIP_OK(hipMemcpy(d_tokens_.p, tokens, (size_t)N * 4, hipMemcpyHostToDevice), err, -1);
     HIP_OK(hipMemcpy(d_cu_.p, cu, 8, hipMemcpyHostToDevice), err, -1);

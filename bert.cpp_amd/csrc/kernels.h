@@ -49,6 +49,10 @@ struct GemmWeight {
 // lda = K, ldc = ldr = N.  MFMA path requires K % 64 == 0.
 void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
                       int M_pad, int epilogue, hipStream_t stream);
+// Large-tile variant (gemm256.hip): 256 x 256 x 64 tiles, 8 waves; f16 weights, N % 256 == 0, M_pad % 256 == 0.
+bool gemm256_supported(const GemmWeight &W, int M_pad);
+void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
+                    int epilogue, hipStream_t stream);
 // Whole FFN block + residual + LayerNorm in one kernel (ffn_fused.hip); y and out must differ.
 bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2);
 void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,

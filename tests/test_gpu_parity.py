@@ -41,10 +41,10 @@ def _gelu(x):
     return 0.5 * x * (1 + np.tanh(0.7978845608028654 * x * (1 + 0.044715 * x * x)))
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2], ids=["mfma", "naive", "panel"])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3], ids=["mfma", "naive", "panel", "tile256"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1", "f32"])
 @pytest.mark.parametrize("shape", [(200, 192, 128), (256, 384, 384), (130, 64, 64), (512, 1536, 384), (384, 384, 1536),
-                                   (256, 1152, 384), (129, 2304, 768)])
+                                   (256, 1152, 384), (129, 2304, 768), (300, 768, 3072), (513, 3072, 768), (256, 256, 64)])
 def test_gemm_kernel(impl, ftype, shape):
     M, N, K = shape
     rng = np.random.default_rng(hash((M, N, K, ftype)) % 2 ** 31)
@@ -57,13 +57,13 @@ def test_gemm_kernel(impl, ftype, shape):
     resid = rng.normal(0, 1, (M, N)).astype(np.float16)
     wb, wdeq = _weight_bytes(W, ftype)
     base = A.astype(np.float64) @ wdeq.astype(np.float64).T + bias
-    for epi in ((0,) if impl == 2 else (0, 1, 2)):
+    for epi in ((0,) if impl == 2 else (0, 1, 2)):      # (the row-panel kernel has the plain epilogue only)
         want = base if epi == 0 else _gelu(base) if epi == 1 else base + resid.astype(np.float64)
         try:
             got = pybert.test_gemm(A, wb, WT[ftype], N, bias, resid if epi == 2 else None, epi, impl).astype(np.float64)
         except RuntimeError as e:
-            if impl == 2 and "-2" in str(e):
-                pytest.skip("shape not handled by the row-panel kernel")
+            if impl in (2, 3) and "-2" in str(e):
+                pytest.skip("shape / weight type not handled by this kernel")
             raise
         err = np.abs(got - want)
         tol = 2e-3 * np.abs(want) + 4e-3          # f16 output rounding + f16 weight rounding of the q4 dequant
