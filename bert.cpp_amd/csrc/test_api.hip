@@ -278,6 +278,47 @@ int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t
 }
 
 
+int32_t bert_hip_test_embed_ln(int32_t table_type, int32_t H, int32_t n_vocab, int32_t n_pos, const void *word, const void *type,
+                               const void *pos, const float *gamma, const float *beta, const bert_vocab_id *tokens,
+                               const int32_t *cu_seqlens, int32_t n_sentences, uint16_t *out) {
+    std::string err;
+    const int T = cu_seqlens[n_sentences];
+    int max_len = 0;
+    for (int b = 0; b < n_sentences; ++b) max_len = std::max(max_len, cu_seqlens[b + 1] - cu_seqlens[b]);
+    const size_t rb = wtype_row_bytes(table_type, H);
+    DevBuf dw, dt, dp, dg, db, dtok, dcu, dout;
+    if (!dw.upload(word, rb * n_vocab, err) || !dt.upload(type, rb * 2, err) || !dp.upload(pos, rb * n_pos, err) ||
+        !dg.upload(gamma, (size_t)H * 4, err) || !db.upload(beta, (size_t)H * 4, err) || !dtok.upload(tokens, (size_t)T * 4, err) ||
+        !dcu.upload(cu_seqlens, (size_t)(n_sentences + 1) * 4, err) || !dout.alloc((size_t)T * H * 2, err)) {
+        fprintf(stderr, "bert_hip_test_embed_ln: %s\n", err.c_str());
+        return -1;
+    }
+    launch_embed_ln(dw.p, dt.p, dp.p, table_type, dg.as<float>(), db.as<float>(), dtok.as<int32_t>(), dcu.as<int32_t>(), n_sentences,
+                    T, H, n_vocab, max_len, dout.as<half_t>(), nullptr);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)T * H * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t bert_hip_test_pool_normalize(int32_t H, const uint16_t *x, const int32_t *cu_seqlens, int32_t n_sentences, int32_t max_len,
+                                     float *out, int32_t *status) {
+    std::string err;
+    const int T = cu_seqlens[n_sentences];
+    DevBuf dx, dcu, dout, dst;
+    if (!dx.upload(x, (size_t)T * H * 2, err) || !dcu.upload(cu_seqlens, (size_t)(n_sentences + 1) * 4, err) ||
+        !dout.alloc((size_t)n_sentences * H * 4, err) || !dst.alloc(16, err)) {
+        fprintf(stderr, "bert_hip_test_pool_normalize: %s\n", err.c_str());
+        return -1;
+    }
+    launch_pool_normalize(dx.as<half_t>(), dcu.as<int32_t>(), n_sentences, H, max_len, dst.as<int>(), dout.as<float>(), nullptr);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(out, dout.p, (size_t)n_sentences * H * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(status, dst.p, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards, int32_t *bounds) {
     std::vector<int> b;
     shard_bounds(cu_seqlens, n_sentences, n_shards, b);

@@ -30,7 +30,7 @@ BERT_HIP_H_SYMBOLS = [
 BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
-    "bert_hip_test_dispatch",
+    "bert_hip_test_dispatch", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
 ]
 TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so"
 
@@ -115,6 +115,10 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_qkv_attention.argtypes = [i32, i32p, i32, i32, vp, vp, i32, vp, i32, vp]
     L.bert_hip_test_layer_tail.restype = i32
     L.bert_hip_test_layer_tail.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.bert_hip_test_embed_ln.restype = i32
+    L.bert_hip_test_embed_ln.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32p, i32p, i32, vp]
+    L.bert_hip_test_pool_normalize.restype = i32
+    L.bert_hip_test_pool_normalize.argtypes = [i32, vp, i32p, i32, i32, vp, i32p]
     L.bert_hip_test_shard_bounds.restype = None
     L.bert_hip_test_shard_bounds.argtypes = [i32p, i32, i32, i32p]
     L.bert_hip_test_build_windows.restype = i32
@@ -123,6 +127,29 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_dispatch.argtypes = [i32p, i32p, i32, i32, i32, C.POINTER(C.c_float)]
     _test_lib = L
     return L
+
+
+def test_embed_ln(table_type: int, word_bytes, type_bytes, pos_bytes, H: int, gamma, beta, tokens, cu_seqlens) -> np.ndarray:
+    wb, tb, pb = (np.ascontiguousarray(a) for a in (word_bytes, type_bytes, pos_bytes))
+    rb = {0: 4 * H, 1: 2 * H, 2: H // 32 * 18, 3: H // 32 * 20}[table_type]
+    g = np.ascontiguousarray(gamma, dtype=np.float32); b = np.ascontiguousarray(beta, dtype=np.float32)
+    toks = np.ascontiguousarray(tokens, dtype=np.int32); cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    out = np.zeros((len(toks), H), dtype=np.float16)
+    r = test_lib().bert_hip_test_embed_ln(table_type, H, wb.nbytes // rb, pb.nbytes // rb, wb.ctypes.data, tb.ctypes.data, pb.ctypes.data,
+                                          g.ctypes.data, b.ctypes.data, _i32p(toks), _i32p(cu), len(cu) - 1, out.ctypes.data)
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_embed_ln failed: {r}")
+    return out
+
+
+def test_pool_normalize(x: np.ndarray, cu_seqlens, max_len: int):
+    x = np.ascontiguousarray(x, dtype=np.float16); cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
+    out = np.zeros((len(cu) - 1, x.shape[1]), dtype=np.float32)
+    st = np.zeros(1, dtype=np.int32)
+    r = test_lib().bert_hip_test_pool_normalize(x.shape[1], x.ctypes.data, _i32p(cu), len(cu) - 1, max_len, out.ctypes.data, _i32p(st))
+    if r != 0:
+        raise RuntimeError(f"bert_hip_test_pool_normalize failed: {r}")
+    return out, int(st[0])
 
 
 def shard_bounds(cu_seqlens: np.ndarray, n_shards: int) -> List[int]:

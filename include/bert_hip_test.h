@@ -59,6 +59,17 @@ BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const
  * (tuning helper of tools/bench_ffn.py; negative on error).                                              */
 BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters);
 
+/* Embedding gather-sum + LayerNorm (reference bert.cpp:796-814): tables in the file layout of `table_type` (0 f32, 1 f16,
+ * 2 q4_0, 3 q4_1), word [n_vocab][H], type [2][H], pos [n_pos][H]; packed sentences; out [T][H] f16 bits.               */
+BERT_API int32_t bert_hip_test_embed_ln(int32_t table_type, int32_t H, int32_t n_vocab, int32_t n_pos, const void *word,
+                                        const void *type, const void *pos, const float *gamma, const float *beta,
+                                        const bert_vocab_id *tokens, const int32_t *cu_seqlens, int32_t n_sentences,
+                                        uint16_t *out);
+/* Mean-pool + L2 normalise (reference bert.cpp:904-913) of x [T][H] f16 bits -> out [n_sentences][H] f32; *status receives
+ * the device status word (1 if a sentence length is outside [1, max_len]: its row is NaN).                              */
+BERT_API int32_t bert_hip_test_pool_normalize(int32_t H, const uint16_t *x, const int32_t *cu_seqlens, int32_t n_sentences,
+                                              int32_t max_len, float *out, int32_t *status);
+
 /* Host logic of the multi-GPU layer and of the sentence windows, callable without a GPU:
  * shard bounds [n_shards + 1] of a packed batch (multi_device.h), and the {first, count} windows of 128 token slots
  * (engine.h build_windows; returns their number, `windows` holds 2 ints per window, capacity n_sentences).        */

@@ -331,6 +331,48 @@ def test_attention_generic_head_dim():
     assert np.abs(got - _attention_ref(qkv, cu, 4, 16)).max() < 6e-3
 
 
+@pytest.mark.parametrize("ftype", ["f32", "f16", "q4_0", "q4_1"])
+@pytest.mark.parametrize("H", [64, 384, 768])
+def test_embed_layernorm_kernel(ftype, H):
+    """word[id] + type[0] + pos[p] -> LayerNorm(eps 1e-5) * gamma + beta (reference bert.cpp:796-814) against float64 on
+    the dequantised tables: every table type the file format has, positions up to 511, ragged sentences."""
+    rng = np.random.default_rng(H + len(ftype))
+    V, P = 300, 512
+    lens = [512, 1, 2, 3, 4, 5, 130, 64, 511]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    toks = rng.integers(0, V, size=int(cu[-1])).astype(np.int32)
+    tabs = [rng.normal(0, 1, (n, H)).astype(np.float32) for n in (V, 2, P)]
+    tabs[2] += np.linspace(-2, 2, P)[:, None].astype(np.float32)           # positions are distinguishable
+    enc = [_weight_bytes(t, ftype) for t in tabs]
+    gamma = rng.normal(1, 0.2, H).astype(np.float32); beta = rng.normal(0, 0.3, H).astype(np.float32)
+    got = pybert.test_embed_ln(WT[ftype], enc[0][0], enc[1][0], enc[2][0], H, gamma, beta, toks, cu).astype(np.float64)
+    word, typ, pos = (e[1].reshape(-1, H).astype(np.float64) for e in enc)
+    p = np.concatenate([np.arange(n) for n in lens])
+    pre = word[toks] + typ[0] + pos[p]
+    mu = pre.mean(axis=1, keepdims=True)
+    want = (pre - mu) / np.sqrt(((pre - mu) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta
+    err = np.abs(got - want)
+    assert err.max() < 4e-3 + 1e-3 * np.abs(want).max(), (ftype, H, float(err.max()), np.argwhere(err > 4e-3)[:4].tolist())
+
+
+@pytest.mark.parametrize("H", [64, 384, 768, 130])
+def test_pool_normalize_kernel(H):
+    """mean over ALL tokens of the sentence, then y / ||y||_2 without epsilon (reference bert.cpp:904-913) against float64;
+    a sentence outside [1, max_len] gets a NaN row and raises the status word."""
+    rng = np.random.default_rng(H)
+    lens = [1, 2, 3, 5, 31, 64, 128, 300, 512]
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = rng.normal(0.1, 1, (int(cu[-1]), H)).astype(np.float16)
+    got, st = pybert.test_pool_normalize(x, cu, 512)
+    assert st == 0
+    for b, n in enumerate(lens):
+        m = x[cu[b]:cu[b + 1]].astype(np.float64).mean(axis=0)
+        want = m / np.sqrt((m * m).sum())
+        assert np.abs(got[b] - want).max() < 2e-6, (H, n, float(np.abs(got[b] - want).max()))
+    got, st = pybert.test_pool_normalize(x, cu, 128)
+    assert st == 1 and np.isnan(got[7]).all() and np.isnan(got[8]).all() and np.isfinite(got[:7]).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # end to end vs the oracle
 # ------------------------------------------------------------------------------------------------
@@ -558,6 +600,31 @@ def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes through size-independent properties
 # ------------------------------------------------------------------------------------------------
+def test_full_size_batch_properties_bert_base(make_model):
+    """configs[3] at full size: bert-base dims q4_1, 512 sentences of 512 tokens.  Unit norm, duplicates give identical
+    bits wherever they sit, the kernels the H = 768 path is meant to use are the ones that ran, and eight sentences spread
+    over the batch agree with the oracle (ggml-faithful mode)."""
+    path, hp = make_model("bert-base", "q4_1", 0)
+    m = pybert.BertModel(path)
+    B, N = 512, 512
+    ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 3)
+    ids[B // 2] = ids[3]
+    ids[B - 1] = ids[3]
+    cu = (np.arange(B + 1) * N).astype(np.int32)
+    m.profile(True)
+    out = m.eval_packed(ids.reshape(-1), cu)
+    rep = m.profile_report()
+    m.profile(False)
+    assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention", "layernorm"} <= set(rep), sorted(rep)
+    assert np.isfinite(out).all()
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
+    assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
+    o = orc.Oracle(path)
+    sample = [0, 3, 77, B // 3, B // 2 + 5, 400, B - 2, B - 1]
+    coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
+    assert min(coss) >= MIN_COS["q4_1"], coss
+
+
 @pytest.mark.parametrize("ftype,B", [("f16", 256), ("q4_0", 1024)])
 def test_full_size_batch_properties(make_model, ftype, B):
     """configs[1] / configs[2]: MiniLM-L6 dims, seq_len 128.  Unit norm, duplicate sentences give

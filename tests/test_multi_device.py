@@ -200,3 +200,45 @@ def test_gemm_option_toggled_after_load(make_model, capfd, monkeypatch):
     assert np.array_equal(m2.eval_batch(s), naive)
     for a, b in zip(naive, fast):
         assert float(a @ b) > 1 - 1e-5
+
+
+def _rank_worker(rank, world, port, model_path, seed, out_dir):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BERT_HIP_DEVICES"] = "0"               # every rank on the one GPU of the test box
+    os.environ["BERT_HIP_QUIET"] = "1"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = pybert.BertModel(model_path)
+        rng = np.random.default_rng(seed)              # same sentences on every rank
+        sents = [rng.integers(1000, 30000, size=int(n)).astype(np.int32) for n in rng.integers(1, 129, size=37)]
+        emb = bdist.encode_sharded(lambda ss: m.eval_batch(ss), sents)
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), emb.numpy())
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ref.npy"), m.eval_batch(sents))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_rank_path_with_the_hip_engine(make_model, tmp_path, world):
+    """The multi-process layer (bert.cpp_amd/dist.py: shard by tokens, evaluate, ONE all-gather) with the real HIP engine
+    in every rank — the ranks share the box's GPU and gather over gloo; on a multi-GPU node the same code runs one rank per
+    GPU over RCCL (bench.py).  Every rank must hold the bits of the single-process evaluation."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    path, hp = make_model("minilm-l6", "f16", 0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, path, 11, str(tmp_path)), nprocs=world, join=True)
+    ref = np.load(tmp_path / "ref.npy")
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), ref), r
