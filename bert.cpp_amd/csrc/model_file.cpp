@@ -108,6 +108,29 @@ bool ModelFile::load(const char *fname, bool vocab_only, std::string &err) {
     const auto expect = expected_tensors(hp);
     tensors.clear();
     total_tensor_bytes = 0;
+    // q4 files exist in two block layouts and the records carry no byte counts: the current one (18-byte q4_0 / 20-byte
+    // q4_1 blocks: f16 scales, nibbles j | j+16 per byte) and the one of early-2023 ggml (20 / 24 bytes: f32 scales, nibbles
+    // 2j | 2j+1 — the sizes the reference's README prints are these, README.md:105-107).  Every expected tensor appears
+    // exactly once, so the length of the tensor section tells the two apart.
+    legacy_q4 = false;
+    if (hp.f16 == W_Q4_0 || hp.f16 == W_Q4_1) {
+        size_t cur = 0, leg = 0;
+        for (const auto &kv : expect) {
+            const Expect &e = kv.second;
+            const size_t hdr = 12 + 4 * (e.two_d ? 2 : 1) + kv.first.size();
+            if (e.two_d && e.ne0 % 32 == 0) {
+                const size_t nblk = (size_t)(e.ne0 / 32) * e.ne1;
+                cur += hdr + nblk * (hp.f16 == W_Q4_0 ? 18 : 20);
+                leg += hdr + nblk * (hp.f16 == W_Q4_0 ? 20 : 24);
+            } else {
+                cur += hdr + (size_t)e.ne0 * e.ne1 * 4;
+                leg += hdr + (size_t)e.ne0 * e.ne1 * 4;
+            }
+        }
+        const size_t have = (size_t)(c.end - c.p);
+        if (have == leg && have != cur) legacy_q4 = true;
+    }
+    converted.clear();
     while (c.p < c.end) {
         int32_t n_dims = 0, name_len = 0, ftype = 0;
         if (!c.take(&n_dims, 4) || !c.take(&name_len, 4) || !c.take(&ftype, 4)) { err = "truncated tensor header"; return false; }
@@ -142,12 +165,36 @@ bool ModelFile::load(const char *fname, bool vocab_only, std::string &err) {
         }
         if ((ftype == W_Q4_0 || ftype == W_Q4_1) && ne[0] % 32 != 0) { err = "tensor '" + name + "': row length not a multiple of 32"; return false; }
         const size_t nbytes = wtype_row_bytes(ftype, ne[0]) * (size_t)ne[1];
-        if ((size_t)(c.end - c.p) < nbytes) { err = "tensor '" + name + "' is truncated"; return false; }
+        const bool legacy = legacy_q4 && (ftype == W_Q4_0 || ftype == W_Q4_1);
+        const size_t file_bytes = legacy ? (size_t)(ne[0] / 32) * ne[1] * (ftype == W_Q4_0 ? 20 : 24) : nbytes;
+        if ((size_t)(c.end - c.p) < file_bytes) { err = "tensor '" + name + "' is truncated"; return false; }
         HostTensor t;
         t.type = ftype; t.n_dims = n_dims; t.ne0 = ne[0]; t.ne1 = ne[1]; t.data = c.p; t.nbytes = nbytes;
+        if (legacy) {
+            // re-block into the current layout (same q's; the f32 scale / minimum are rounded to f16, which is what the
+            // current format stores): everything downstream sees one layout
+            converted.emplace_back(nbytes);
+            uint8_t *dst = converted.back().data();
+            const int nsc = ftype == W_Q4_0 ? 1 : 2, lbs = 4 * nsc + 16, nbs = 2 * nsc + 16;
+            const size_t nblk = (size_t)(ne[0] / 32) * ne[1];
+            for (size_t b = 0; b < nblk; ++b) {
+                const uint8_t *src = c.p + b * lbs;
+                uint8_t *out = dst + b * nbs;
+                for (int k = 0; k < nsc; ++k) {
+                    float v;
+                    memcpy(&v, src + 4 * k, 4);
+                    const _Float16 h = (_Float16)v;
+                    memcpy(out + 2 * k, &h, 2);
+                }
+                uint8_t el[32];
+                for (int j = 0; j < 16; ++j) { el[2 * j] = src[4 * nsc + j] & 0x0F; el[2 * j + 1] = src[4 * nsc + j] >> 4; }
+                for (int j = 0; j < 16; ++j) out[2 * nsc + j] = (uint8_t)(el[j] | (el[j + 16] << 4));
+            }
+            t.data = dst;
+        }
         tensors[name] = t;
         total_tensor_bytes += nbytes;
-        c.p += nbytes;
+        c.p += file_bytes;
     }
     // the reference leaves missing tensors uninitialised; fail loudly instead
     for (const auto &kv : expect)

@@ -32,6 +32,8 @@ struct ModelFile {
     std::map<std::string, HostTensor> tensors;
     std::vector<uint8_t> blob;   // whole file; HostTensor::data points into it
     size_t total_tensor_bytes = 0;
+    bool legacy_q4 = false;                          // the file uses the 20 / 24-byte q4 blocks of early-2023 ggml
+    std::vector<std::vector<uint8_t>> converted;     // their tensors, re-blocked into the current layout
 
     // Returns false and fills `err` on any malformed input.  vocab_only stops after the vocab.
     bool load(const char *fname, bool vocab_only, std::string &err);

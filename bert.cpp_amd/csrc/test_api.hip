@@ -319,6 +319,22 @@ int32_t bert_hip_test_pool_normalize(int32_t H, const uint16_t *x, const int32_t
     return 0;
 }
 
+int32_t bert_hip_test_model_digest(const char *fname, int32_t *legacy_q4, uint64_t *digest) {
+    ModelFile mf;
+    std::string err;
+    if (!mf.load(fname, false, err)) { fprintf(stderr, "bert_hip_test_model_digest: %s\n", err.c_str()); return -1; }
+    uint64_t h = 1469598103934665603ull;                       // FNV-1a over name, type and bytes (current layout) of every tensor
+    auto mix = [&](const void *p, size_t n) { for (size_t i = 0; i < n; ++i) { h ^= ((const uint8_t *)p)[i]; h *= 1099511628211ull; } };
+    for (const auto &kv : mf.tensors) {
+        mix(kv.first.data(), kv.first.size());
+        mix(&kv.second.type, 4);
+        mix(kv.second.data, kv.second.nbytes);
+    }
+    *legacy_q4 = mf.legacy_q4 ? 1 : 0;
+    *digest = h;
+    return (int32_t)mf.tensors.size();
+}
+
 void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards, int32_t *bounds) {
     std::vector<int> b;
     shard_bounds(cu_seqlens, n_sentences, n_shards, b);

@@ -96,6 +96,23 @@ def dequantize_q4_1(b: np.ndarray) -> np.ndarray:
     return vals.reshape(*b.shape[:-2], b.shape[-2] * QK)
 
 
+# Legacy block layouts (ggml before May 2023; the model sizes the reference's README prints, README.md:105-107, are
+# these): block_q4_0 = { f32 d; u8 qs[16] } = 20 B, block_q4_1 = { f32 d; f32 m; u8 qs[16] } = 24 B, and byte qs[j] holds
+# elements 2j (low nibble) and 2j+1 (high nibble) instead of j and j+16.
+def to_legacy_q4(b: np.ndarray, ftype: int) -> np.ndarray:
+    """uint8 [..., nb, 18|20] (current layout) -> uint8 [..., nb, 20|24] (legacy layout), same q's, d / m widened to f32."""
+    bs = 18 if ftype == FTYPE_Q4_0 else 20
+    flat = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, bs)
+    nsc = 1 if ftype == FTYPE_Q4_0 else 2
+    sc = flat[:, : 2 * nsc].copy().view(np.float16).astype(np.float32)         # [nblk, nsc]
+    qs = flat[:, 2 * nsc:]
+    el = np.concatenate([qs & 0x0F, qs >> 4], axis=1)                          # elements 0..31
+    out = np.empty((flat.shape[0], 4 * nsc + 16), dtype=np.uint8)
+    out[:, : 4 * nsc] = sc.view(np.uint8).reshape(-1, 4 * nsc)
+    out[:, 4 * nsc:] = el[:, 0::2] | (el[:, 1::2] << 4)
+    return out.reshape(*b.shape[:-1], 4 * nsc + 16)
+
+
 # --------------------------------------------------------------------------------------------
 # model description
 # --------------------------------------------------------------------------------------------
@@ -227,7 +244,7 @@ def _encode_2d(a: np.ndarray, ftype: int) -> bytes:
 
 
 def write_model(path: str, hp: BertHParams, weights: Dict[str, np.ndarray], ftype: int,
-                vocab: Optional[Sequence[bytes]] = None, from_f16: bool = True) -> None:
+                vocab: Optional[Sequence[bytes]] = None, from_f16: bool = True, legacy_q4: bool = False) -> None:
     """Write a bert.cpp model file.  2-D tensors named '*weight' take `ftype`; 1-D stay f32.
 
     For q4 types the source is first rounded through f16 when `from_f16` (the reference pipeline
@@ -257,7 +274,11 @@ def write_model(path: str, hp: BertHParams, weights: Dict[str, np.ndarray], ftyp
                 src = a
                 if t in (FTYPE_Q4_0, FTYPE_Q4_1) and from_f16:
                     src = a.astype(np.float16).astype(np.float32)
-                f.write(_encode_2d(src, t))
+                data = _encode_2d(src, t)
+                if legacy_q4 and t in (FTYPE_Q4_0, FTYPE_Q4_1):
+                    bs = 18 if t == FTYPE_Q4_0 else 20
+                    data = to_legacy_q4(np.frombuffer(data, dtype=np.uint8).reshape(-1, bs), t).tobytes()
+                f.write(data)
             else:
                 f.write(a.tobytes())
 

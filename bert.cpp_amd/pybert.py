@@ -31,6 +31,7 @@ BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
     "bert_hip_test_dispatch", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
+    "bert_hip_test_model_digest",
 ]
 TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so"
 
@@ -119,6 +120,8 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_embed_ln.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, i32p, i32p, i32, vp]
     L.bert_hip_test_pool_normalize.restype = i32
     L.bert_hip_test_pool_normalize.argtypes = [i32, vp, i32p, i32, i32, vp, i32p]
+    L.bert_hip_test_model_digest.restype = i32
+    L.bert_hip_test_model_digest.argtypes = [C.c_char_p, i32p, C.POINTER(C.c_uint64)]
     L.bert_hip_test_shard_bounds.restype = None
     L.bert_hip_test_shard_bounds.argtypes = [i32p, i32, i32, i32p]
     L.bert_hip_test_build_windows.restype = i32
@@ -150,6 +153,16 @@ def test_pool_normalize(x: np.ndarray, cu_seqlens, max_len: int):
     if r != 0:
         raise RuntimeError(f"bert_hip_test_pool_normalize failed: {r}")
     return out, int(st[0])
+
+
+def model_digest(path: str):
+    """(n_tensors, legacy_q4, digest) of a model file as the product's parser sees it (no GPU needed)."""
+    leg = C.c_int32(0)
+    dig = C.c_uint64(0)
+    n = test_lib().bert_hip_test_model_digest(path.encode(), C.byref(leg), C.byref(dig))
+    if n < 0:
+        raise RuntimeError("model file rejected (see stderr)")
+    return n, bool(leg.value), int(dig.value)
 
 
 def shard_bounds(cu_seqlens: np.ndarray, n_shards: int) -> List[int]:

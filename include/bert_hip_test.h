@@ -70,6 +70,10 @@ BERT_API int32_t bert_hip_test_embed_ln(int32_t table_type, int32_t H, int32_t n
 BERT_API int32_t bert_hip_test_pool_normalize(int32_t H, const uint16_t *x, const int32_t *cu_seqlens, int32_t n_sentences,
                                               int32_t max_len, float *out, int32_t *status);
 
+/* Parses a model file (no GPU): returns the number of tensors (negative on error, message on stderr), whether the file uses the
+ * legacy 20 / 24-byte q4 blocks, and a digest of every tensor's name, type and bytes AFTER conversion to the current layout.   */
+BERT_API int32_t bert_hip_test_model_digest(const char *fname, int32_t *legacy_q4, uint64_t *digest);
+
 /* Host logic of the multi-GPU layer and of the sentence windows, callable without a GPU:
  * shard bounds [n_shards + 1] of a packed batch (multi_device.h), and the {first, count} windows of 128 token slots
  * (engine.h build_windows; returns their number, `windows` holds 2 ints per window, capacity n_sentences).        */

@@ -558,6 +558,17 @@ def test_q4_expanded_at_load_equals_fused_dequant(make_model, dims, ftype, monke
         assert cosine(a[i], want) > 0.99 and cosine(b[i], want) > 0.99
 
 
+@pytest.mark.parametrize("ftype", ["q4_0", "q4_1"])
+def test_legacy_q4_files_load_and_give_the_same_embeddings(tmp_path, ftype):
+    hp = gf.MODEL_DIMS["tiny-h128"]
+    w = gf.synthetic_weights(hp, 3)
+    cur, leg = str(tmp_path / "cur.bin"), str(tmp_path / "leg.bin")
+    gf.write_model(cur, hp, w, gf.FTYPE_BY_NAME[ftype])
+    gf.write_model(leg, hp, w, gf.FTYPE_BY_NAME[ftype], legacy_q4=True)
+    sents = [np.random.default_rng(1).integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (5, 64, 33)]
+    assert np.array_equal(pybert.BertModel(cur).eval_batch(sents), pybert.BertModel(leg).eval_batch(sents))
+
+
 @pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL", "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
 def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
     """The fused kernels each have a fallback family (token-owning layer tail -> 128-token panel kernels -> tiled GEMMs

@@ -204,3 +204,30 @@ def test_load_fails_loudly_without_gpu(tmp_path, capfd):
     out = m.eval([101, 5, 102])
     assert np.isnan(out).all()
     assert "no device weights" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("ftype", ["q4_0", "q4_1"])
+def test_legacy_q4_block_layout_is_detected_and_converted(tmp_path, ftype):
+    """Model files quantised by early-2023 ggml use 20-byte q4_0 / 24-byte q4_1 blocks (f32 scales, nibbles 2j | 2j+1): the
+    sizes the reference's README prints (README.md:105-107).  The records carry no byte counts; the loader tells the layouts
+    apart by the length of the tensor section and re-blocks legacy tensors, after which they are byte-identical to the same
+    weights written in the current layout."""
+    from bert_cpp_amd import ggml_file as gf
+
+    hp = gf.MODEL_DIMS["tiny-h128"]
+    w = gf.synthetic_weights(hp, 3)
+    cur, leg = str(tmp_path / "cur.bin"), str(tmp_path / "leg.bin")
+    gf.write_model(cur, hp, w, gf.FTYPE_BY_NAME[ftype])
+    gf.write_model(leg, hp, w, gf.FTYPE_BY_NAME[ftype], legacy_q4=True)
+    assert os.path.getsize(leg) > os.path.getsize(cur)
+    n0, l0, d0 = libbert.model_digest(cur)
+    n1, l1, d1 = libbert.model_digest(leg)
+    assert (n0, l0) == (5 + 16 * hp.n_layer, False) and (n1, l1) == (n0, True)
+    assert d0 == d1
+    # a legacy file cut short is still rejected
+    data = open(leg, "rb").read()
+    bad = str(tmp_path / "bad.bin")
+    open(bad, "wb").write(data[:-100])
+    with silenced_stderr():
+        with pytest.raises(RuntimeError):
+            libbert.model_digest(bad)
