@@ -47,6 +47,9 @@ from bert_cpp_amd import ggml_file as gf  # noqa: E402
 from bert_cpp_amd import pybert  # noqa: E402
 
 MFMA_PEAK_F16 = 2.5e15      # dense, /opt/skills/guides/MI355X_MICROARCH.md §Matrix cores
+# What the matrix cores sustain on RANDOM f16 operands under the board's power limit: v_mfma_f32_32x32x16_f16 back to back from
+# registers, nothing else running (tools/ubench/mfma_power.hip, profiles/r2_mfma_power.txt: 1644 TFLOP/s; 2465 on zeros).
+MFMA_RATE_RANDOM_F16 = 1.644e15
 
 # BASELINE.json configs[1..4]; configs[0] is the CPU-only plumbing case (= the cpu_baseline leg).
 CONFIGS = {
@@ -203,6 +206,7 @@ def kernel_roofline(res, torch, device, steps=5):
     key = res["cfg"].get("key", f"config{res['cfg_id']}")
     roof = {"bound": "mfma", "kernel": name, "achieved": achieved / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
             "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_F16, "traffic": committed_traffic(key, name),
+            "mfma_rate_under_power_limit": MFMA_RATE_RANDOM_F16 / 1e12, "frac_of_that": achieved / MFMA_RATE_RANDOM_F16,
             "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops,
             "kernel_time_share": st["total_ms"] / total_ms if total_ms else None}
     breakdown = {k: round(v["total_ms"] / steps, 4) for k, v in sorted(rep.items())}
