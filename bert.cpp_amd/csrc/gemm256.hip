@@ -18,6 +18,8 @@
 // back to back): the activation tile then comes from HBM once, not once per XCD.
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace bert_hip {
 
 namespace {
@@ -54,13 +56,6 @@ __device__ __forceinline__ void g2_dma_tile(const half_t *src, int ld, char *til
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + (size_t)r * ld + c * 8), G2_LDS(tile + g * 1024), 16, 0, 0);
     }
-}
-
-__device__ __forceinline__ float g2_gelu(float x) {
-    const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
-    const float c2 = c1 * 0.044715f;
-    const float t = x * __builtin_fmaf(x * x, c2, c1);
-    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
 }
 
 __device__ __forceinline__ int g2_xcd_remap(int bid, int nblocks) {
@@ -128,7 +123,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // ---- epilogue: two passes of 128 feature columns through LDS as f32 [256 tokens][32 chunks of 4 floats], the chunk
     // index XORed with (token & 31): conflict-free for the accumulator-layout writes and for the row-wise reads
     float *Cs = (float *)smem;
-    for (int pass = 0; pass < 2; ++pass) {
+    const int chunk = tid & 31, trow = tid >> 5;
+    // the residual rows of a pass are requested BEFORE its accumulators go through LDS (pass 1: before pass 0's rows are
+    // finished): sixteen dependent load -> add -> store rounds cost a workgroup 17 us of HBM latency (measured: fixed cost
+    // 25.6 us per workgroup against 8.5 us for the plain epilogue), sixteen loads in flight under other work cost nothing
+    f16x4 rv[2][16];
+    auto load_resid = [&](auto pass_tag) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_tag)::value;
+        if (EPI == EPI_BIAS_RESID) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rv[pass][s] = *(const f16x4 *)(p.resid + ((size_t)m0 + s * 16 + trow) * p.N + n0 + pass * 128 + chunk * 4);
+        }
+    };
+    auto stage = [&](int pass) __attribute__((always_inline)) {
         if (wf == pass) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -137,41 +144,53 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                     const int tok = wq * 64 + j * 32 + l31;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const int chunk = i * 8 + g * 2 + hi;                 // features 4 * chunk .. + 3 of this pass
+                        const int ch = i * 8 + g * 2 + hi;                    // features 4 * ch .. + 3 of this pass
                         f32x4 v;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                        *(f32x4 *)(Cs + tok * 128 + ((chunk ^ (tok & 31)) << 2)) = v;
+                        *(f32x4 *)(Cs + tok * 128 + ((ch ^ (tok & 31)) << 2)) = v;
                     }
                 }
         }
-        __syncthreads();
-        const int chunk = tid & 31;
+    };
+    auto finish = [&](auto pass_tag) __attribute__((always_inline)) {
+        constexpr int pass = decltype(pass_tag)::value;
         const int f0 = n0 + pass * 128 + chunk * 4;
         const f32x4 bv = *(const f32x4 *)(p.bias + f0);
-#pragma unroll 4
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int tok = s * 16 + (tid >> 5);
+            const int tok = s * 16 + trow;
             f32x4 v = *(const f32x4 *)(Cs + tok * 128 + ((chunk ^ (tok & 31)) << 2));
             const size_t off = ((size_t)m0 + tok) * p.N + f0;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = g2_gelu(v[e]);
-            }
             if (EPI == EPI_BIAS_RESID) {
-                const f16x4 rv = *(const f16x4 *)(p.resid + off);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                for (int e = 0; e < 4; ++e) v[e] += (float)rv[pass][s][e];
             }
             f16x4 o;
+            if (EPI == EPI_BIAS_GELU) {
+                // packed f16, as layer_tail.hip evaluates it (the reference reads the GELU from an f16 table)
+                const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
+                o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+            }
             *(f16x4 *)(p.C + off) = o;
         }
-        __syncthreads();
-    }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    load_resid(P0{});
+    stage(0);
+    __syncthreads();
+    load_resid(P1{});
+    finish(P0{});
+    __syncthreads();
+    stage(1);
+    __syncthreads();
+    finish(P1{});
 }
 
 bool gemm256_supported(const GemmWeight &W, int M_pad) {
