@@ -180,6 +180,47 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             *(f16x4 *)(p.C + off) = o;
         }
     };
+    if constexpr (EPI != EPI_BIAS_RESID) {
+        // no residual: bias (and GELU) in the accumulator layout, then the whole 256 x 256 tile goes through LDS ONCE as f16
+        // ([256 tokens][32 chunks of 8 features], chunk index XORed with token & 31), and every global store is 16 bytes of a
+        // full 512-byte row segment.  Same arithmetic (f32 bias add, one rounding), half the LDS traffic and barriers of the
+        // two-pass f32 form below.
+        char *Ch = smem;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 bq[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4 *)(p.bias + n0 + wf * 128 + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int tok = wq * 64 + j * 32 + l31;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[g][e];
+                    f16x4 o;
+                    if (EPI == EPI_BIAS_GELU) {
+                        const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
+                        o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
+                    }
+                    const int c = wf * 16 + i * 4 + g;                        // 16-byte chunk (8 features) of the row
+                    *(f16x4 *)(Ch + tok * 512 + ((c ^ (tok & 31)) << 4) + hi * 8) = o;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int tok = s * 16 + trow;
+            const uint4 v = *(const uint4 *)(Ch + tok * 512 + ((chunk ^ (tok & 31)) << 4));
+            *(uint4 *)(p.C + ((size_t)m0 + tok) * p.N + n0 + chunk * 8) = v;
+        }
+        return;
+    }
     using P0 = std::integral_constant<int, 0>;
     using P1 = std::integral_constant<int, 1>;
     load_resid(P0{});
