@@ -59,7 +59,8 @@ public:
                          std::string &err, float *d_embeddings = nullptr);
     // device-resident, asynchronous on `stream`
     // d_windows / n_windows: optional sentence windows of the fused projection+attention kernel (build_windows), in
-    // device memory; without them sentences are placed by the uniform rule of qkv_attention2.hip
+    // device memory; without them the same windows are built on the device (launch_build_windows) when the batch is
+    // short enough on average for packing to pay, else sentences are placed by the uniform rule of qkv_attention2.hip
     int eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int n_sentences, int n_tokens, int max_len,
                            float *d_out, hipStream_t stream, float *d_hidden, std::string &err,
                            const int2 *d_windows = nullptr, int n_windows = 0);
@@ -94,7 +95,7 @@ private:
     std::vector<LayerWeights *> layers_;
 
     // workspace (grow-only)
-    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_, status_;
+    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_;
     hipStream_t stream_ = nullptr;
     // the workspace serves ONE forward pass at a time: every pass waits for the previous one's event on its own stream
     hipEvent_t busy_ = nullptr;

@@ -288,7 +288,8 @@ void Engine::set_option(const std::string &key, const std::string &value) {
 bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
     return x_.ensure(tp * H * 2, err) && qkv_.ensure(tp * 3 * H * 2, err) && ctx_.ensure(tp * H * 2, err) &&
-           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && d_out_.ensure((size_t)n_sentences * H * 4, err);
+           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && d_out_.ensure((size_t)n_sentences * H * 4, err) &&
+           windows_.ensure((size_t)n_sentences * sizeof(int2), err);
 }
 
 template <class F>
@@ -378,12 +379,27 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     tap(0);
     // attention FLOPs: 4 * sum_b N_b^2 * H; only T and max_len are known here -> upper bound T * max_len
     const double att_flops = 4.0 * Td * max_len * H;
+    // sentence windows of the fused projection+attention kernel: the caller's (host path), or built here on the device from
+    // cu_seqlens when packing can pay — sentences on average clearly shorter than max_len; for full-length batches the
+    // uniform rule (max_len-sized places) gives the same windows without the extra launch
+    const int *d_n_windows = nullptr;
+    if (!d_windows && qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok &&
+        qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len)) {
+        const int spw = qkv_attention2_sentences_per_window(max_len), uniform = (B + spw - 1) / spw;
+        if (4ll * uniform * 128 > 5 * ((long long)T + 8ll * B)) {
+            int *count = status_.as<int>() + 1;
+            timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, s); });
+            d_windows = windows_.as<int2>();
+            d_n_windows = count;
+            n_windows = std::min(uniform, qkv_attention2_max_windows(B, T));   // next-fit never needs more windows than the uniform rule
+        }
+    }
     for (int il = 0; il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
         if (qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths
             timed("qkv_attention2", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
-                launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, max_len, nh, ctx, s);
+                launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, d_n_windows, max_len, nh, ctx, s);
             });
         } else
         // one workgroup per sentence pays for 128 tokens whatever the length: worth it from ~48 tokens on average

@@ -117,9 +117,14 @@ void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *
 // 128 / round_up(max_len, 16) sentences per window.
 bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);
 int qkv_attention2_sentences_per_window(int max_len);
+// n_groups_dev (optional): device word with the real number of windows when `groups` was built on the device and n_groups is
+// only an upper bound (launch_build_windows / qkv_attention2_max_windows).
 void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
-                           int n_sentences, const int2 *groups, int n_groups, int max_len, int n_head, half_t *out,
-                           hipStream_t stream);
+                           int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
+                           half_t *out, hipStream_t stream);
+// next-fit windows (the rule of Engine::build_windows) computed on the device from cu_seqlens; *n_windows receives their number
+void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream);
+int qkv_attention2_max_windows(int n_sentences, int n_tokens);
 
 // mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].  A sentence whose length is not in
 // [1, max_len] (the caller of the device API promised max_len) gets a NaN row and sets *status (device word) to 1.

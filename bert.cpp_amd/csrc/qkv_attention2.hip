@@ -52,6 +52,7 @@ struct Qkv2Args {
     const float *bias;       // [3H]
     const int32_t *cu;       // [n_sent + 1]
     const int2 *groups;      // per workgroup {first sentence, count}; nullptr: `spw` sentences per workgroup
+    const int *n_groups;     // device word holding the number of windows (device-built windows: the grid is an upper bound), or nullptr
     half_t *out;             // [T_pad][H] attention context
     int n_head, n_sent, spw;
 };
@@ -140,7 +141,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
 
     // ---- the window: sentences first .. first+count-1, sentence j at slots [off_j, off_j + n_j)
     int first, count;
-    if (a.groups) { const int2 g = a.groups[blockIdx.x]; first = g.x; count = g.y; }
+    if (a.groups) {
+        if (a.n_groups && (int)blockIdx.x >= *a.n_groups) {   // beyond the windows the device-side builder produced
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        const int2 g = a.groups[blockIdx.x];
+        first = g.x; count = g.y;
+    }
     else { first = blockIdx.x * a.spw; count = min(a.spw, a.n_sent - first); }
     if (count <= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (never taken by the launcher's grids) the DMA must not outlive the workgroup
@@ -453,6 +461,76 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Next-fit windows built ON THE DEVICE (the asynchronous device API has the sentence lengths in HBM only): the same rule as
+// Engine::build_windows — sentences in order, each starting at a multiple of 16 slots, the open window is closed when the next
+// sentence does not fit into its 128 slots.  Next-fit is a sequential automaton, but its state is tiny (the fill of the open
+// window: 0, 16, ... 128 slots), so it parallelises as a scan over state maps: every thread runs its block of sentences from
+// ALL nine entry states at once and records where each ends up, how many windows it closes and which sentence opened the
+// window it leaves open; thread 0 chains the per-block maps; every thread then replays its block from its true entry state
+// and writes the windows it closes.
+constexpr int BW_THREADS = 512, BW_STATES = 9;
+
+__global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t *__restrict__ cu, int B, int2 *__restrict__ windows,
+                                                                   int *__restrict__ n_windows) {
+    __shared__ unsigned char exit_state[BW_THREADS][BW_STATES];   // fill / 16 after the block
+    __shared__ int closes[BW_THREADS][BW_STATES];                 // windows closed inside the block
+    __shared__ int opened[BW_THREADS][BW_STATES];                 // first sentence of the window left open; -1: the entry window
+    __shared__ int entry_fill[BW_THREADS], entry_first[BW_THREADS], entry_index[BW_THREADS];
+    const int t = threadIdx.x, per = (B + BW_THREADS - 1) / BW_THREADS, n_blocks = per ? (B + per - 1) / per : 0;
+    const int b0 = min(B, t * per), b1 = min(B, b0 + per);
+
+    int fill[BW_STATES], n_closed[BW_STATES], first[BW_STATES];
+#pragma unroll
+    for (int e = 0; e < BW_STATES; ++e) { fill[e] = e * 16; n_closed[e] = 0; first[e] = -1; }
+    for (int b = b0; b < b1; ++b) {
+        const int n = cu[b + 1] - cu[b];
+#pragma unroll
+        for (int e = 0; e < BW_STATES; ++e) {
+            if (fill[e] == 0) first[e] = b;                       // an empty window opens at this sentence
+            else if (fill[e] + n > 128) { ++n_closed[e]; first[e] = b; fill[e] = 0; }
+            fill[e] = min(128, (fill[e] + n + 15) & ~15);         // (no sentence is longer than a window here)
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < BW_STATES; ++e) {
+        exit_state[t][e] = (unsigned char)(fill[e] / 16); closes[t][e] = n_closed[e]; opened[t][e] = first[e];
+    }
+    __syncthreads();
+    if (t == 0) {
+        int e = 0, open_first = 0, index = 0;
+        for (int k = 0; k < n_blocks; ++k) {
+            entry_fill[k] = e * 16; entry_first[k] = open_first; entry_index[k] = index;
+            index += closes[k][e];
+            if (opened[k][e] >= 0) open_first = opened[k][e];
+            e = exit_state[k][e];
+        }
+        if (B > 0) windows[index++] = make_int2(open_first, B - open_first);   // the window still open after the last sentence
+        *n_windows = index;
+    }
+    __syncthreads();
+    if (b0 < b1) {
+        int f = entry_fill[t], open_first = entry_first[t], index = entry_index[t];
+        for (int b = b0; b < b1; ++b) {
+            const int n = cu[b + 1] - cu[b];
+            if (f == 0) open_first = b;
+            else if (f + n > 128) { windows[index++] = make_int2(open_first, b - open_first); open_first = b; f = 0; }
+            f = min(128, (f + n + 15) & ~15);
+        }
+    }
+}
+
+void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream) {
+    hipLaunchKernelGGL(build_windows_kernel, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
+}
+
+int qkv_attention2_max_windows(int n_sentences, int n_tokens) {
+    // two consecutive next-fit windows hold more than 128 slots together
+    const long long slots = (long long)n_tokens + 15ll * n_sentences;
+    const long long bound = 2 * (slots / 128) + 2;
+    return (int)(bound < n_sentences ? bound : n_sentences);
+}
+
 bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len) {
     const int H = n_head * d_head;
     return Wqkv.type == GW_F16 && d_head == 32 && Wqkv.K == H && Wqkv.N == 3 * H && (H == 128 || H == 256 || H == 384) &&
@@ -462,10 +540,10 @@ bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, in
 int qkv_attention2_sentences_per_window(int max_len) { return Q2_WIN / ((max_len + 15) & ~15); }
 
 void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
-                           int n_sentences, const int2 *groups, int n_groups, int max_len, int n_head, half_t *out,
-                           hipStream_t stream) {
+                           int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
+                           half_t *out, hipStream_t stream) {
     Qkv2Args a;
-    a.x = x; a.w = Wqkv.w16; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.out = out;
+    a.x = x; a.w = Wqkv.w16; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.n_groups = n_groups_dev; a.out = out;
     a.n_head = n_head; a.n_sent = n_sentences;
     a.spw = qkv_attention2_sentences_per_window(max_len);
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;

@@ -30,6 +30,7 @@ BERT_HIP_H_SYMBOLS = [
 BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
+    "bert_hip_test_build_windows_device",
     "bert_hip_test_dispatch", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
     "bert_hip_test_model_digest",
 ]
@@ -126,6 +127,8 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_shard_bounds.argtypes = [i32p, i32, i32, i32p]
     L.bert_hip_test_build_windows.restype = i32
     L.bert_hip_test_build_windows.argtypes = [i32p, i32, i32p]
+    L.bert_hip_test_build_windows_device.restype = i32
+    L.bert_hip_test_build_windows_device.argtypes = [i32p, i32, i32p]
     L.bert_hip_test_dispatch.restype = i32
     L.bert_hip_test_dispatch.argtypes = [i32p, i32p, i32, i32, i32, C.POINTER(C.c_float)]
     _test_lib = L
@@ -172,10 +175,14 @@ def shard_bounds(cu_seqlens: np.ndarray, n_shards: int) -> List[int]:
     return out.tolist()
 
 
-def build_windows(cu_seqlens: np.ndarray) -> List[tuple]:
+def build_windows(cu_seqlens: np.ndarray, device: bool = False) -> List[tuple]:
+    """{first sentence, count} windows of 128 token slots: the host builder, or (device=True, needs a GPU) the kernel."""
     cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
     out = np.zeros(2 * max(len(cu) - 1, 1), dtype=np.int32)
-    n = test_lib().bert_hip_test_build_windows(_i32p(cu), len(cu) - 1, _i32p(out))
+    f = test_lib().bert_hip_test_build_windows_device if device else test_lib().bert_hip_test_build_windows
+    n = f(_i32p(cu), len(cu) - 1, _i32p(out))
+    if n < 0:
+        raise RuntimeError("bert_hip_test_build_windows_device failed")
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
 

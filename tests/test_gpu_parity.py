@@ -256,7 +256,7 @@ Q2_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", [2, 3], ids=["next-fit", "uniform"])
+@pytest.mark.parametrize("mode", [2, 3, 4], ids=["next-fit", "uniform", "next-fit-on-device"])
 @pytest.mark.parametrize("n_head", [4, 8, 12])
 @pytest.mark.parametrize("lens", Q2_CASES, ids=[f"case{i}" for i in range(len(Q2_CASES))])
 def test_qkv_attention2_kernel(n_head, lens, mode):
@@ -281,6 +281,23 @@ def test_qkv_attention2_kernel(n_head, lens, mode):
     assert err.max() < 6e-3, (n_head, mode, float(err.max()), bad[:8].tolist(), len(bad))
     neq = np.argwhere(got.view(np.uint16) != split.view(np.uint16))
     assert len(neq) == 0, (n_head, mode, len(neq), neq[:8].tolist())
+
+
+@pytest.mark.parametrize("n_sentences", [1, 2, 7, 511, 512, 513, 1024, 5000, 40000])
+@pytest.mark.parametrize("dist", ["short", "mixed", "full", "sixteens"])
+def test_windows_built_on_the_device_equal_the_host_builder(n_sentences, dist):
+    """The device API packs sentences into 128-slot windows with a kernel (a scan over the next-fit automaton's nine
+    states, qkv_attention2.hip build_windows_kernel); the host path with a loop (engine.hip build_windows): same list."""
+    rng = np.random.default_rng(n_sentences * 7 + len(dist))
+    lens = {"short": lambda: rng.integers(1, 20, n_sentences),
+            "mixed": lambda: np.clip(rng.gamma(2.0, 14.0, n_sentences).astype(np.int64) + 1, 1, 128),
+            "full": lambda: rng.integers(120, 129, n_sentences),
+            "sixteens": lambda: rng.choice([15, 16, 17, 32, 48, 64, 112, 128], n_sentences)}[dist]()
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    host = pybert.build_windows(cu)
+    dev = pybert.build_windows(cu, device=True)
+    assert dev == host, (len(dev), len(host), next((i, a, b) for i, (a, b) in enumerate(zip(dev, host)) if a != b) if len(dev) == len(host) else None)
+    assert sum(c for _, c in dev) == n_sentences
 
 
 def test_qkv_attention2_same_bits_in_any_window():

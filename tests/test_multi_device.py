@@ -164,6 +164,29 @@ def test_device_api_guards(make_model, capfd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mean_len", [6, 25, 90])
+def test_device_api_packs_short_sentences_like_the_host_api(make_model, mean_len):
+    """The asynchronous device API sees the lengths only in HBM: it builds the 128-slot windows with a kernel (when the batch
+    is short enough for packing to pay) and must give the bits of the host API, which builds them on the CPU."""
+    hip = _Hip()
+    path, hp = make_model("minilm-l6", "f16", 0)
+    m = pybert.BertModel(path)
+    rng = np.random.default_rng(mean_len)
+    lens = np.clip(rng.gamma(2.0, mean_len / 2.0, 1500).astype(np.int64) + 1, 1, 128)
+    cu = _cu(lens)
+    T, H = int(cu[-1]), hp.n_embd
+    toks = rng.integers(1000, hp.n_vocab, size=T).astype(np.int32)
+    want = m.eval_packed(toks, cu)
+    d_t, d_cu = hip.upload(toks), hip.upload(cu)
+    out = hip.upload(np.full((len(lens), H), 7.0, np.float32))
+    m.reserve(T, len(lens))
+    for _ in range(3):                                      # (the window list is rebuilt by every pass)
+        m.eval_packed_device(d_t, d_cu, len(lens), T, 128, out, 0)
+    assert m.check() == 0
+    assert np.array_equal(hip.download(out, (len(lens), H)), want)
+
+
+@pytest.mark.gpu
 def test_no_exception_crosses_the_abi(make_model, capfd, monkeypatch):
     path, hp = make_model("tiny", "f16", 1)
     m = pybert.BertModel(path)
