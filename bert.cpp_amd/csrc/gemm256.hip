@@ -10,12 +10,18 @@
 //   * v_mfma_f32_32x32x16_f16 with the WEIGHT tile as the A operand and the ACTIVATION tile as the B operand: a lane's
 //     accumulator column is one token, its registers are 4-feature runs (bias / GELU / residual per lane, f32);
 //   * tiles go HBM/L2 -> LDS by global_load_lds_dwordx4, double buffered (2 x 64 KiB), one barrier per reduction tile,
-//     the 16-byte chunk swizzle on the SOURCE address (the DMA writes lane-linearly) and again on the fragment reads;
-//   * epilogue: the f32 tile goes through LDS in two passes of 128 feature columns (the tile buffers are free by then),
-//     so every global access of the output and of the residual is a full 512-byte row segment; bias, GELU and the
-//     residual are applied in f32 and the result is rounded once, exactly as gemm.hip does.
-// Workgroups are remapped so that each XCD walks a contiguous range of logical tiles (all feature tiles of a token tile
-// back to back): the activation tile then comes from HBM once, not once per XCD.
+//     the 16-byte chunk swizzle on the SOURCE address (the DMA writes lane-linearly) and again on the fragment reads; the
+//     fragments of a k-step are read (hand-issued ds_read_b128, counted waits) under the MFMAs of the one before, and the
+//     last k-step of a reduction tile runs behind the next tile's barrier, under that tile's first reads;
+//   * ONE PERSISTENT WORKGROUP PER CU walks its share of the output tiles (each XCD a contiguous range, all feature tiles
+//     of a token tile back to back: an activation tile comes from HBM once, not once per XCD) and the stream of reduction
+//     tiles runs across output tiles without a gap — no workgroup launch, prologue latency or drained pipeline per tile;
+//   * epilogue: bias, GELU and the residual are applied in f32 in the accumulator layout and rounded once (as gemm.hip
+//     does), then a wave passes its own 64 tokens x 128 features through a private 4 KiB staging area in four rounds, so
+//     every global store is 16 bytes of a full 128-byte row segment; no barrier, no use of the tile buffers.
+// Measured (bert-base, 512 x 512 tokens, per reduction tile 1.45 us = 88 % of the matrix rate the board sustains at its
+// power limit; hipBLASLt's 256x256x64 kernel on the same shapes: QKV 836 us, this kernel 960): what is left is the epilogue
+// — 128 store instructions per tile at 31-52 cycles each per CU (tools/ubench/store_issue.hip) with no MFMA beside them.
 #include "kernels.h"
 
 #include <type_traits>
@@ -42,200 +48,298 @@ struct Gemm256Args {
     const float *bias;      // [N]
     const half_t *resid;    // [M_pad][N] or null
     half_t *C;              // [M_pad][N]
-    int N, K, n_tiles_n;
+    int N, K, n_tiles_n, n_tiles;
 };
-
-__device__ __forceinline__ int g2_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// 256 rows x 128 B: 32 pieces of 1 KiB (8 rows each), 4 per wave
-__device__ __forceinline__ void g2_dma_tile(const half_t *src, int ld, char *tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int g = wave * 4 + i;
-        const int r = g * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + (size_t)r * ld + c * 8), G2_LDS(tile + g * 1024), 16, 0, 0);
-    }
-}
-
-__device__ __forceinline__ int g2_xcd_remap(int bid, int nblocks) {
-    const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 }  // namespace
 
+// G2_ABLATE (tuning builds only, results are wrong): bit 0 no global stores in the epilogue, bit 1 no epilogue at all,
+// bit 2 no residual loads, bit 3 no LDS staging (the stores write whatever the staging area holds) — what a component costs is the time its removal saves (tools/variant.sh)
+#ifndef G2_ABLATE
+#define G2_ABLATE 0
+#endif
+// stores of an epilogue left in flight across the first barrier behind it (16 = all of a wave's, 0 = none)
+#ifndef G2_STORES_IN_FLIGHT
+#define G2_STORES_IN_FLIGHT 16
+#endif
+
+// ---- hand-issued fragment reads (the compiler does not track them: every wait names the registers it releases)
+template <int OFF>
+__device__ __forceinline__ f16x8 g2_read_b128(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+struct G2Frag {
+    f16x8 a[4], b[2];                                  // weight rows (4 x 32 features), activation rows (2 x 32 tokens) of one k-step
+};
+// everything but the newest six reads (the next k-step's) has landed
+__device__ __forceinline__ void g2_wait6(G2Frag &f) {
+    asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
+}
+__device__ __forceinline__ void g2_wait0(G2Frag &f) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
+}
+// reduction-tile barrier: this wave's pieces of the tile have landed, its reads of the previous one have returned (the
+// fragments of that tile's last k-step are named: their MFMAs run after the barrier, under the first reads of the new tile)
+template <int VM = 0>
+__device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
+    asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : "n"(VM) : "memory");
+}
+
+// A PERSISTENT workgroup per CU walks its share of the output tiles (each XCD a contiguous range: all feature tiles of a
+// token tile back to back, so an activation tile comes from HBM once); the stream of reduction tiles runs across output
+// tiles without a gap: the first reduction tile of the next output tile is requested during the last one of the current,
+// and the epilogue of a finished output tile runs after the NEXT tile's first barrier — its global stores are then
+// retired under a whole reduction tile of MFMAs instead of in front of a barrier.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lb = g2_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = lb % p.n_tiles_n, mt = lb / p.n_tiles_n;
-    const int m0 = mt * G2_BM, n0 = nt * G2_BN;
-    const int K = p.K, nk = K / G2_BK;
     const int wf = wave & 1, wq = wave >> 1;         // feature half (128) / token quarter (64) of the tile
     const int l31 = lane & 31, hi = lane >> 5;
+    const int K = p.K, nk = K / G2_BK;
 
-    const half_t *Abase = p.A + (size_t)m0 * K;
-    const half_t *Wbase = p.w16 + (size_t)n0 * K;
+    // ---- this workgroup's output tiles: t_first, t_first + S, ... below t_end
+    const int xcd = blockIdx.x & 7, S = gridDim.x >> 3;
+    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
+    int tile = t_begin + (int)(blockIdx.x >> 3);
+    if (tile >= t_end) return;
 
-    f32x16 acc[4][2];                                 // [feature block][token block]
+    // ---- LDS-DMA: a reduction tile is 2 x 32 pieces of 1 KiB (8 rows each), 4 + 4 per wave; source offsets (elements)
+    unsigned doff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        doff[i] = (unsigned)(r * K + (((lane & 7) ^ ((r >> 1) & 7)) << 3));
+    }
+    auto dma_piece = [&](const half_t *src, char *stage_base, auto i_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value;       // 0..3: activation pieces, 4..7: weight pieces
+        __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + doff[i & 3]), G2_LDS(stage_base + (i >> 2) * G2_TILE + (wave * 4 + (i & 3)) * 1024), 16, 0, 0);
+    };
 
-    g2_dma_tile(Abase, K, smem, wave, lane);
-    g2_dma_tile(Wbase, K, smem + G2_TILE, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        char *cur = smem + (kt & 1) * G2_STAGE;
-        char *nxt = smem + ((kt + 1) & 1) * G2_STAGE;
-        if (kt + 1 < nk) {                            // the next tile's traffic first: it lands under this tile's MFMAs
-            g2_dma_tile(Abase + (kt + 1) * G2_BK, K, nxt, wave, lane);
-            g2_dma_tile(Wbase + (kt + 1) * G2_BK, K, nxt + G2_TILE, wave, lane);
-        }
-        const char *At = cur, *Wt = cur + G2_TILE;
+    // ---- fragment addresses of the four k-steps of a reduction tile (stage 0; the other stage is address ^ 64 KiB)
+    unsigned aW[4], aA[4];
+    {
+        const int s = (l31 >> 1) & 7;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int c = kk * 2 + hi;
-            f16x8 a[4], b[2];
+            const unsigned swz = (unsigned)((((kk * 2 + hi) ^ s) << 4));
+            aA[kk] = (unsigned)(size_t)smem + (unsigned)((wq * 64 + l31) * 128) + swz;      // (LDS addresses are 32-bit)
+            aW[kk] = (unsigned)(size_t)smem + (unsigned)(G2_TILE + (wf * 128 + l31) * 128) + swz;
+        }
+    }
+    auto read_frag = [&](G2Frag &f, auto kk_tag) __attribute__((always_inline)) {
+        constexpr int kk = decltype(kk_tag)::value;
+        f.a[0] = g2_read_b128<0>(aW[kk]); f.a[1] = g2_read_b128<4096>(aW[kk]);
+        f.a[2] = g2_read_b128<8192>(aW[kk]); f.a[3] = g2_read_b128<12288>(aW[kk]);
+        f.b[0] = g2_read_b128<0>(aA[kk]); f.b[1] = g2_read_b128<4096>(aA[kk]);
+    };
+
+    f32x16 acc[4][2];                                 // [feature block][token block]
+    auto mfma_step = [&](const G2Frag &f) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *(const f16x8 *)(Wt + g2_off(wf * 128 + i * 32 + l31, c));
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = *(const f16x8 *)(At + g2_off(wq * 64 + j * 32 + l31, c));
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+    };
+
+    // ---- epilogue of the output tile at (em0, en0): bias (+ GELU | + residual) in f32 in the accumulator layout (lane =
+    // token, registers = 4-feature runs), one rounding, then through a wave-private 4 KiB staging area in four rounds of
+    // [32 tokens][64 features] so that every global store is 16 bytes of a full 128-byte row segment.  No barrier: a wave
+    // stages and stores its own 64 tokens x 128 features.
+    char *const stg = smem + 2 * G2_STAGE + wave * 4096;
+    auto epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
+        // (opaque copies: every address below is computed here, not hoisted out of the tile loop into registers that
+        // the accumulators need)
+        int l31 = lane & 31, hi = lane >> 5, lane_e = lane;
+        asm volatile("" : "+v"(l31), "+v"(hi), "+v"(lane_e));
+        if (G2_ABLATE & 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) asm volatile("" : : "v"(acc[i][j]));
+            return;
+        }
+        // phase 1, registers only: EVERY load of the epilogue (bias, residual) is issued and consumed before the first
+        // store — vmcnt retires in issue order, so a load behind a store would wait for that store's acknowledgement
+        // (measured: the residual form cost 16-25 us per tile with loads and stores alternating round by round)
+        f16x4 o[2][2][2][4];                               // [ip][j][ii][g]: 64 registers, the accumulators' own as they die
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip) {
+            f32x4 bq[2][4];
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[ii][g] = *(const f32x4 *)(p.bias + en0 + wf * 128 + (2 * ip + ii) * 32 + 8 * g + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x4 rv[2][4];
+                if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
+                    const half_t *rrow = p.resid + ((size_t)em0 + wq * 64 + j * 32 + l31) * p.N + en0 + wf * 128 + 4 * hi;
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) rv[ii][g] = *(const f16x4 *)(rrow + (2 * ip + ii) * 32 + 8 * g);
+                }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[2 * ip + ii][j][4 * g + e] + bq[ii][g][e];
+                        if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[ii][g][e];
+                        }
+                        if (EPI == EPI_BIAS_GELU) {
+                            // packed f16, as layer_tail.hip evaluates it (the reference reads the GELU from an f16 table)
+                            const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
+                            o[ip][j][ii][g][0] = g0[0]; o[ip][j][ii][g][1] = g0[1]; o[ip][j][ii][g][2] = g1[0]; o[ip][j][ii][g][3] = g1[1];
+                            __builtin_amdgcn_sched_barrier(0);   // one run at a time: the GELU temporaries of several would spill
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[ip][j][ii][g][e] = (_Float16)v[e];
+                        }
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2, no loads: four rounds of [32 tokens][64 features] through the staging area
+#pragma unroll
+        for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (G2_ABLATE & 8) asm volatile("" : : "v"(o[ip][j][ii][g]));
+                        else *(f16x4 *)(stg + l31 * 128 + (((ii * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = o[ip][j][ii][g];
+                    }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                half_t *crow = (G2_ABLATE & 16) ? p.C + ((size_t)blockIdx.x * 256 + wq * 64 + j * 32) * p.N + wf * 128 + ip * 64   // (every tile of a workgroup to one place)
+                                                : p.C + ((size_t)em0 + wq * 64 + j * 32) * p.N + en0 + wf * 128 + ip * 64;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane_e >> 3), ch = lane_e & 7;
+                    const uint4 v = *(const uint4 *)(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+                    if (G2_ABLATE & 1) asm volatile("" : : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    else *(uint4 *)(crow + (size_t)row * p.N + ch * 8) = v;
+                }
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+
+    // (a one-time start delay that spreads the workgroups' phases over a tile period was tried: no gain — the cost of an
+    // epilogue is its CU's own store issue, 31 B/cycle/CU into L2 and 18 when the whole chip streams to HBM,
+    // tools/ubench/store_issue.hip — not the other CUs' bursts)
+    int m0 = (tile / p.n_tiles_n) * G2_BM, n0 = (tile % p.n_tiles_n) * G2_BN;
+    {   // the first reduction tile of the first output tile
+        const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
+        dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
+        dma_piece(w, smem, I4{}); dma_piece(w, smem, I5{}); dma_piece(w, smem, I6{}); dma_piece(w, smem, I7{});
+    }
+    G2Frag f0, f1;
+    bool have_prev = false;
+    int pm0 = 0, pn0 = 0;
+    // k-steps 0..2 of a reduction tile whose first fragments (f0) have been requested; leaves the last k-step's fragments
+    // (f1) in flight: its MFMAs run after the next barrier.  Then the fragment addresses move to the other stage.
+    auto steps_0_to_2 = [&]() __attribute__((always_inline)) {
+        read_frag(f1, I1{}); g2_wait6(f0); mfma_step(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f0, I2{}); g2_wait6(f1); mfma_step(f1);
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag(f1, I3{}); g2_wait6(f0); mfma_step(f0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { aA[kk] ^= (unsigned)G2_STAGE; aW[kk] ^= (unsigned)G2_STAGE; }
+    };
+    int stage = 0;
+    for (;;) {
+        const int next = tile + S;
+        const bool more = next < t_end;
+        // (after the last output tile the stream requests this tile's first reduction tile once more: a request that
+        // is never read costs less than a branch around every request)
+        const int nm0 = more ? (next / p.n_tiles_n) * G2_BM : m0, nn0 = more ? (next % p.n_tiles_n) * G2_BN : n0;
+        const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
+        {   // ---- reduction tile 0: the previous output tile is finished behind its barrier
+            g2_tile_barrier(f1);
+            const half_t *na = ta + G2_BK, *nw = tw + G2_BK;
+            char *nstage = smem + (stage ^ 1) * G2_STAGE;
+            dma_piece(na, nstage, I0{}); dma_piece(na, nstage, I1{}); dma_piece(na, nstage, I2{}); dma_piece(na, nstage, I3{});
+            dma_piece(nw, nstage, I4{}); dma_piece(nw, nstage, I5{}); dma_piece(nw, nstage, I6{}); dma_piece(nw, nstage, I7{});
+            if (have_prev) {
+                mfma_step(f1);                         // the last k-step of the previous output tile
+                epilogue(pm0, pn0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            read_frag(f0, I0{});
+            steps_0_to_2();
+            stage ^= 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        for (int kt = 1; kt < nk; ++kt) {
+            // (vmcnt retires in issue order) reduction tile 1 was requested before the previous output tile's 16 stores:
+            // they stay in flight across this barrier and have until the next one to be acknowledged
+            if (kt == 1 && have_prev) g2_tile_barrier<G2_STORES_IN_FLIGHT>(f1);
+            else g2_tile_barrier(f1);
+            // the next reduction tile (of this output tile, or the first of the next one) into the stage just released
+            const bool last = kt + 1 == nk;
+            const half_t *na = last ? p.A + (size_t)nm0 * K : ta + (kt + 1) * G2_BK;
+            const half_t *nw = last ? p.w16 + (size_t)nn0 * K : tw + (kt + 1) * G2_BK;
+            char *nstage = smem + (stage ^ 1) * G2_STAGE;
+            read_frag(f0, I0{});
+            // the previous reduction tile's last k-step, with the new tile's requests between its MFMAs
+            dma_piece(na, nstage, I0{}); dma_piece(na, nstage, I1{});
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[0], f1.b[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[0], f1.b[1], acc[0][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(na, nstage, I2{}); dma_piece(na, nstage, I3{});
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[1], f1.b[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[1], f1.b[1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(nw, nstage, I4{}); dma_piece(nw, nstage, I5{});
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[2], f1.b[0], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[2], f1.b[1], acc[2][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            dma_piece(nw, nstage, I6{}); dma_piece(nw, nstage, I7{});
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[3], f1.b[0], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[3], f1.b[1], acc[3][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            steps_0_to_2();
+            stage ^= 1;
+        }
+        have_prev = true; pm0 = m0; pn0 = n0;
+        if (!more) break;
+        tile = next; m0 = nm0; n0 = nn0;
     }
-
-    // ---- epilogue: two passes of 128 feature columns through LDS as f32 [256 tokens][32 chunks of 4 floats], the chunk
-    // index XORed with (token & 31): conflict-free for the accumulator-layout writes and for the row-wise reads
-    float *Cs = (float *)smem;
-    const int chunk = tid & 31, trow = tid >> 5;
-    // the residual rows of a pass are requested BEFORE its accumulators go through LDS (pass 1: before pass 0's rows are
-    // finished): sixteen dependent load -> add -> store rounds cost a workgroup 17 us of HBM latency (measured: fixed cost
-    // 25.6 us per workgroup against 8.5 us for the plain epilogue), sixteen loads in flight under other work cost nothing
-    f16x4 rv[2][16];
-    auto load_resid = [&](auto pass_tag) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pass_tag)::value;
-        if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) rv[pass][s] = *(const f16x4 *)(p.resid + ((size_t)m0 + s * 16 + trow) * p.N + n0 + pass * 128 + chunk * 4);
-        }
-    };
-    auto stage = [&](int pass) __attribute__((always_inline)) {
-        if (wf == pass) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int tok = wq * 64 + j * 32 + l31;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int ch = i * 8 + g * 2 + hi;                    // features 4 * ch .. + 3 of this pass
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                        *(f32x4 *)(Cs + tok * 128 + ((ch ^ (tok & 31)) << 2)) = v;
-                    }
-                }
-        }
-    };
-    auto finish = [&](auto pass_tag) __attribute__((always_inline)) {
-        constexpr int pass = decltype(pass_tag)::value;
-        const int f0 = n0 + pass * 128 + chunk * 4;
-        const f32x4 bv = *(const f32x4 *)(p.bias + f0);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int tok = s * 16 + trow;
-            f32x4 v = *(const f32x4 *)(Cs + tok * 128 + ((chunk ^ (tok & 31)) << 2));
-            const size_t off = ((size_t)m0 + tok) * p.N + f0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += bv[e];
-            if (EPI == EPI_BIAS_RESID) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)rv[pass][s][e];
-            }
-            f16x4 o;
-            if (EPI == EPI_BIAS_GELU) {
-                // packed f16, as layer_tail.hip evaluates it (the reference reads the GELU from an f16 table)
-                const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
-                o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-            }
-            *(f16x4 *)(p.C + off) = o;
-        }
-    };
-    if constexpr (EPI != EPI_BIAS_RESID) {
-        // no residual: bias (and GELU) in the accumulator layout, then the whole 256 x 256 tile goes through LDS ONCE as f16
-        // ([256 tokens][32 chunks of 8 features], chunk index XORed with token & 31), and every global store is 16 bytes of a
-        // full 512-byte row segment.  Same arithmetic (f32 bias add, one rounding), half the LDS traffic and barriers of the
-        // two-pass f32 form below.
-        char *Ch = smem;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 bq[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4 *)(p.bias + n0 + wf * 128 + i * 32 + 8 * g + 4 * hi);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int tok = wq * 64 + j * 32 + l31;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[g][e];
-                    f16x4 o;
-                    if (EPI == EPI_BIAS_GELU) {
-                        const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
-                        o[0] = g0[0]; o[1] = g0[1]; o[2] = g1[0]; o[3] = g1[1];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                    }
-                    const int c = wf * 16 + i * 4 + g;                        // 16-byte chunk (8 features) of the row
-                    *(f16x4 *)(Ch + tok * 512 + ((c ^ (tok & 31)) << 4) + hi * 8) = o;
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int tok = s * 16 + trow;
-            const uint4 v = *(const uint4 *)(Ch + tok * 512 + ((chunk ^ (tok & 31)) << 4));
-            *(uint4 *)(p.C + ((size_t)m0 + tok) * p.N + n0 + chunk * 8) = v;
-        }
-        return;
-    }
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    load_resid(P0{});
-    stage(0);
-    __syncthreads();
-    load_resid(P1{});
-    finish(P0{});
-    __syncthreads();
-    stage(1);
-    __syncthreads();
-    finish(P1{});
+    // the request issued behind the last output tile must not outlive the workgroup
+    g2_tile_barrier(f1);
+    mfma_step(f1);
+    epilogue(pm0, pn0);
 }
 
 bool gemm256_supported(const GemmWeight &W, int M_pad) {
-    return W.type == GW_F16 && W.w16 && W.N % G2_BN == 0 && W.K % G2_BK == 0 && M_pad % G2_BM == 0 && M_pad > 0;
+    return W.type == GW_F16 && W.w16 && W.N % G2_BN == 0 && W.K % G2_BK == 0 && W.K >= 2 * G2_BK && M_pad % G2_BM == 0 && M_pad > 0;
 }
 
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
@@ -243,8 +347,18 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     Gemm256Args a;
     a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C;
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
-    const int grid = a.n_tiles_n * (M_pad / G2_BM);
-    const size_t lds = 2 * G2_STAGE;                  // 128 KiB
+    a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
+    // one persistent workgroup per CU (256 on an MI355X, a multiple of the 8 XCDs), fewer when there are fewer tiles
+    static int n_cu[MAX_HIP_DEVICES] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < MAX_HIP_DEVICES && !n_cu[dev]) {
+        hipDeviceProp_t prop;
+        n_cu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
+    const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
+    const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
     static bool configured[3][MAX_HIP_DEVICES] = {};
     auto go = [&](auto kernel, int e) {
         if (first_launch_on_device(configured[e]))

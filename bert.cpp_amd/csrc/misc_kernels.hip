@@ -120,17 +120,32 @@ __device__ __forceinline__ void table_run8(const void *tab, int H, int r, int e0
         for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
     }
 }
-template <int TT, int NC>
+// SEARCH: the grid is (4-token group of the batch) and a wave finds its sentence by bisection of cu_seqlens on scalar loads
+// — for batches of short sentences, where the (group, sentence) grid would be mostly empty workgroups.
+template <int TT, int NC, bool SEARCH>
 __global__ __launch_bounds__(256) void embed_ln_rows_kernel(const void *word, const void *type, const void *pos,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             const int32_t *__restrict__ tokens,
-                                                            const int32_t *__restrict__ cu_seqlens, int H, int n_vocab,
-                                                            half_t *__restrict__ out) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // position in the sentence
-    const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
-    if (p >= n) return;
-    const int t = tok0 + p;
+                                                            const int32_t *__restrict__ cu_seqlens, int n_sentences, int T,
+                                                            int H, int n_vocab, half_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // position in the sentence / token
+    int t;
+    if constexpr (SEARCH) {
+        t = p;
+        if (t >= T) return;
+        int lo = 0, hi = n_sentences;                         // largest b with cu[b] <= t
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (cu_seqlens[mid] <= t) lo = mid; else hi = mid;
+        }
+        p = t - cu_seqlens[lo];
+    } else {
+        const int b = blockIdx.y;
+        const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
+        if (p >= n) return;
+        t = tok0 + p;
+    }
     int id = tokens[t];
     id = id < 0 ? 0 : (id >= n_vocab ? n_vocab - 1 : id);   // ids are validated on the host API; clamp for safety
     float v[NC][8];
@@ -177,10 +192,15 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
                      const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
                      int H, int n_vocab, int max_len, half_t *out, hipStream_t stream) {
     if (T <= 0) return;
-    if (table_type <= 1 && H % 8 == 0 && H <= 1024 && max_len > 0 && n_sentences <= 65535) {
-        const dim3 g2((max_len + 3) / 4, n_sentences), b2(256);
-#define EMBR(TT, NC) hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
-                                        cu_seqlens, H, n_vocab, out)
+    if (table_type <= 1 && H % 8 == 0 && H <= 1024 && max_len > 0) {
+        // (group, sentence) grid while at least two thirds of its workgroups have tokens, else one group per 4 tokens
+        const bool search = n_sentences > 65535 || 2ll * ((max_len + 3) / 4) * n_sentences > 3ll * ((T + 3) / 4);
+        const dim3 g2 = search ? dim3((T + 3) / 4) : dim3((max_len + 3) / 4, n_sentences), b2(256);
+#define EMBR(TT, NC) do { \
+            if (search) hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC, true>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
+                                           cu_seqlens, n_sentences, T, H, n_vocab, out); \
+            else hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC, false>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
+                                    cu_seqlens, n_sentences, T, H, n_vocab, out); } while (0)
         if (table_type == 0) { if (H <= 512) EMBR(0, 1); else EMBR(0, 2); }
         else { if (H <= 512) EMBR(1, 1); else EMBR(1, 2); }
 #undef EMBR
