@@ -22,17 +22,17 @@ __device__ __forceinline__ float rounded_f32(float v) {
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 // tanh-form GELU of two values, packed f16: x / (1 + 2^(x (c1 + c2 x^2)))
-__device__ __forceinline__ f16x2_t gelu_pk16(float a0, float a1) {
+__device__ __forceinline__ f16x2_t gelu_pk16h(f16x2_t xh) {
     const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
     const f16x2_t C1 = {(_Float16)c1, (_Float16)c1}, C2 = {(_Float16)(c1 * 0.044715f), (_Float16)(c1 * 0.044715f)};
     const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
-    const f16x2_t xh = {(_Float16)a0, (_Float16)a1};
     const f16x2_t t = (xh * xh * C2 + C1) * xh;
     const f16x2_t e = {(_Float16)__builtin_exp2f16(t[0]), (_Float16)__builtin_exp2f16(t[1])};
     const f16x2_t d = e + one;
     const f16x2_t r = {(_Float16)__builtin_amdgcn_rcph(d[0]), (_Float16)__builtin_amdgcn_rcph(d[1])};
     return xh * r;
 }
+__device__ __forceinline__ f16x2_t gelu_pk16(float a0, float a1) { return gelu_pk16h(f16x2_t{(_Float16)a0, (_Float16)a1}); }
 
 constexpr int GEMM_BM = 128;   // token tile
 constexpr int GEMM_BN = 128;   // feature tile

@@ -71,6 +71,27 @@ def test_gemm_kernel(impl, ftype, shape):
         assert not bad.any(), (ftype, shape, epi, impl, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5])
 
 
+@pytest.mark.parametrize("M,N,K", [(20480, 2304, 768), (33000, 768, 3072), (70000, 768, 768)])
+def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
+    """The 256 x 256 tile kernel runs one persistent workgroup per CU: with more output tiles than CUs a workgroup streams
+    its reduction tiles across output tiles and finishes a tile's epilogue behind the next tile's first barrier.
+    All three epilogues against numpy (float32 BLAS here: the product is too large for a float64 matmul in a test)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.normal(0, 1, (M, K)).astype(np.float16)
+    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float16)
+    W[:, : K // 2] *= 1.5
+    W[: N // 3] += 0.02
+    bias = rng.normal(0, 0.5, N).astype(np.float32)
+    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
+    base = A.astype(np.float32) @ W.astype(np.float32).T + bias
+    for epi in (0, 1, 2):
+        want = base if epi == 0 else _gelu(base.astype(np.float64)).astype(np.float32) if epi == 1 else base + resid.astype(np.float32)
+        got = pybert.test_gemm(A, W.view(np.uint8), 1, N, bias, resid if epi == 2 else None, epi, impl).astype(np.float32)
+        err = np.abs(got - want)
+        bad = err > 2e-3 * np.abs(want) + 4e-3
+        assert not bad.any(), (impl, epi, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["panel", "gemm+ln"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1"])
 @pytest.mark.parametrize("M,N,K", [(200, 128, 64), (256, 384, 384), (130, 256, 512), (384, 384, 1536)])
