@@ -22,7 +22,7 @@
 // Measured (bert-base, 512 x 512 tokens, per reduction tile 1.45 us = 88 % of the matrix rate the board sustains at its
 // power limit; hipBLASLt's 256x256x64 kernel on the same shapes: QKV 836 us, this kernel 960): what is left is the epilogue
 // — 128 store instructions per tile at 31-52 cycles each per CU (tools/ubench/store_issue.hip) with no MFMA beside them.
-#include "kernels.h"
+#include "tile_stream.h"
 
 #include <type_traits>
 
@@ -58,10 +58,25 @@ struct Gemm256Args {
 #ifndef G2_ABLATE
 #define G2_ABLATE 0
 #endif
-// stores of an epilogue left in flight across the first barrier behind it (16 = all of a wave's, 0 = none)
-#ifndef G2_STORES_IN_FLIGHT
-#define G2_STORES_IN_FLIGHT 16
+
+// G2_DMA_PLAN: how many of a wave's 8 LDS-DMA pieces of the next reduction tile are issued in each of the four 8-MFMA steps
+// of a reduction tile (deferred last k-step, k-steps 0, 1, 2), as a 4-digit number.  The CU's vector-memory path takes ~12
+// cycles per piece: all 64 pieces of a tile offered within one step's 256 cycles queue up and the waves wait at the
+// issue (tools/ubench/store_beside_mfma.hip: +590 cycles per tile bunched, +84 spread); too late a piece misses the barrier.
+#ifndef G2_DMA_PLAN
+#define G2_DMA_PLAN 4400
 #endif
+constexpr int g2_plan_count(int step) { return step == 0 ? G2_DMA_PLAN / 1000 : step == 1 ? G2_DMA_PLAN / 100 % 10 : step == 2 ? G2_DMA_PLAN / 10 % 10 : G2_DMA_PLAN % 10; }
+static_assert(g2_plan_count(0) + g2_plan_count(1) + g2_plan_count(2) + g2_plan_count(3) == 8, "a wave issues 8 pieces per reduction tile");
+// the piece issued behind MFMA m (0..7) of `step`, or -1: a step's pieces are spread evenly over its MFMAs
+constexpr int g2_piece_at(int step, int m) {
+    int first = 0;
+    for (int s = 0; s < step; ++s) first += g2_plan_count(s);
+    const int c = g2_plan_count(step);
+    for (int k = 0; k < c; ++k)
+        if ((k * 8) / c == m) return first + k;
+    return -1;
+}
 
 // ---- hand-issued fragment reads (the compiler does not track them: every wait names the registers it releases)
 template <int OFF>
@@ -83,10 +98,9 @@ __device__ __forceinline__ void g2_wait0(G2Frag &f) {
 }
 // reduction-tile barrier: this wave's pieces of the tile have landed, its reads of the previous one have returned (the
 // fragments of that tile's last k-step are named: their MFMAs run after the barrier, under the first reads of the new tile)
-template <int VM = 0>
 __device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
-    asm volatile("s_waitcnt vmcnt(%6) lgkmcnt(0)\n\ts_barrier"
-                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : "n"(VM) : "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+                 : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
 }
 
 // A PERSISTENT workgroup per CU walks its share of the output tiles (each XCD a contiguous range: all feature tiles of a
@@ -143,6 +157,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     };
 
     f32x16 acc[4][2];                                 // [feature block][token block]
+    // the 8 MFMAs of a k-step with `fill(m)` pinned behind MFMA m
+    auto mfma_step_with = [&](const G2Frag &f, auto fill) __attribute__((always_inline)) {
+        static_for<8>([&](auto m_tag) __attribute__((always_inline)) {
+            constexpr int m = decltype(m_tag)::value, i = m >> 1, j = m & 1;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
+            fill(m_tag);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
     auto mfma_step = [&](const G2Frag &f) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -259,13 +282,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     int pm0 = 0, pn0 = 0;
     // k-steps 0..2 of a reduction tile whose first fragments (f0) have been requested; leaves the last k-step's fragments
     // (f1) in flight: its MFMAs run after the next barrier.  Then the fragment addresses move to the other stage.
-    auto steps_0_to_2 = [&]() __attribute__((always_inline)) {
-        read_frag(f1, I1{}); g2_wait6(f0); mfma_step(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(f0, I2{}); g2_wait6(f1); mfma_step(f1);
-        __builtin_amdgcn_sched_barrier(0);
-        read_frag(f1, I3{}); g2_wait6(f0); mfma_step(f0);
-        __builtin_amdgcn_sched_barrier(0);
+    // the pieces of the next reduction tile that G2_DMA_PLAN puts into `step`, each behind its MFMA
+    auto dma_fill = [&](const half_t *na, const half_t *nw, char *nstage, auto step_tag, auto m_tag) __attribute__((always_inline)) {
+        constexpr int piece = g2_piece_at(decltype(step_tag)::value, decltype(m_tag)::value);
+        if constexpr (piece >= 0) dma_piece(piece < 4 ? na : nw, nstage, std::integral_constant<int, (piece >= 0 ? piece : 0)>{});
+    };
+    auto steps_0_to_2 = [&](const half_t *na, const half_t *nw, char *nstage) __attribute__((always_inline)) {
+        read_frag(f1, I1{}); g2_wait6(f0);
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I1{}, m); });
+        read_frag(f0, I2{}); g2_wait6(f1);
+        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I2{}, m); });
+        read_frag(f1, I3{}); g2_wait6(f0);
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I3{}, m); });
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { aA[kk] ^= (unsigned)G2_STAGE; aW[kk] ^= (unsigned)G2_STAGE; }
     };
@@ -281,8 +309,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             g2_tile_barrier(f1);
             const half_t *na = ta + G2_BK, *nw = tw + G2_BK;
             char *nstage = smem + (stage ^ 1) * G2_STAGE;
-            dma_piece(na, nstage, I0{}); dma_piece(na, nstage, I1{}); dma_piece(na, nstage, I2{}); dma_piece(na, nstage, I3{});
-            dma_piece(nw, nstage, I4{}); dma_piece(nw, nstage, I5{}); dma_piece(nw, nstage, I6{}); dma_piece(nw, nstage, I7{});
+            // (this tile's step-0 pieces go out in one go: with a previous output tile its last k-step and epilogue follow,
+            // without one there is nothing to put them between)
+            static_for<g2_plan_count(0)>([&](auto i) __attribute__((always_inline)) {
+                constexpr int piece = decltype(i)::value;
+                dma_piece(piece < 4 ? na : nw, nstage, i);
+            });
             if (have_prev) {
                 mfma_step(f1);                         // the last k-step of the previous output tile
                 epilogue(pm0, pn0);
@@ -294,38 +326,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             read_frag(f0, I0{});
-            steps_0_to_2();
+            steps_0_to_2(na, nw, nstage);
             stage ^= 1;
         }
         for (int kt = 1; kt < nk; ++kt) {
-            // (vmcnt retires in issue order) reduction tile 1 was requested before the previous output tile's 16 stores:
-            // they stay in flight across this barrier and have until the next one to be acknowledged
-            if (kt == 1 && have_prev) g2_tile_barrier<G2_STORES_IN_FLIGHT>(f1);
-            else g2_tile_barrier(f1);
+            g2_tile_barrier(f1);
             // the next reduction tile (of this output tile, or the first of the next one) into the stage just released
             const bool last = kt + 1 == nk;
             const half_t *na = last ? p.A + (size_t)nm0 * K : ta + (kt + 1) * G2_BK;
             const half_t *nw = last ? p.w16 + (size_t)nn0 * K : tw + (kt + 1) * G2_BK;
             char *nstage = smem + (stage ^ 1) * G2_STAGE;
             read_frag(f0, I0{});
-            // the previous reduction tile's last k-step, with the new tile's requests between its MFMAs
-            dma_piece(na, nstage, I0{}); dma_piece(na, nstage, I1{});
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[0], f1.b[0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[0], f1.b[1], acc[0][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_piece(na, nstage, I2{}); dma_piece(na, nstage, I3{});
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[1], f1.b[0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[1], f1.b[1], acc[1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_piece(nw, nstage, I4{}); dma_piece(nw, nstage, I5{});
-            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[2], f1.b[0], acc[2][0], 0, 0, 0);
-            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[2], f1.b[1], acc[2][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            dma_piece(nw, nstage, I6{}); dma_piece(nw, nstage, I7{});
-            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[3], f1.b[0], acc[3][0], 0, 0, 0);
-            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1.a[3], f1.b[1], acc[3][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            steps_0_to_2();
+            // the previous reduction tile's last k-step, with the new tile's first requests between its MFMAs
+            mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I0{}, m); });
+            steps_0_to_2(na, nw, nstage);
             stage ^= 1;
         }
         have_prev = true; pm0 = m0; pn0 = n0;

@@ -11,6 +11,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+#define GLOBAL_AS(p) ((const __attribute__((address_space(1))) void *)(p))
+#define LDS_AS(p) ((__attribute__((address_space(3))) void *)(p))
+// NLOAD: LDS-DMA pieces (1 KiB, global_load_lds_dwordx4) per round besides the stores, from an L2-resident 16 MiB region
+// PHASED: 0 = loads and stores evenly interleaved over the round; p > 0: loads behind MFMAs 0..NLOAD-1, stores behind MFMAs p..p+15
+#ifndef PHASED
+#define PHASED 0
+#endif
+#ifndef NLOAD
+#define NLOAD 0
+#endif
 template <int NSTORE>
 __global__ __launch_bounds__(256) void kernel(char *buf, const f16x8 *src, int rounds, size_t round_stride, int wrap, size_t pitch, long long *cycles, float *sink) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -24,6 +34,8 @@ __global__ __launch_bounds__(256) void kernel(char *buf, const f16x8 *src, int r
     // block (j = (r >> 1) & 3, ip = r & 1): 4 stores of 8 rows x 128 B
     const int wf = wave & 1, wt = wave >> 1;
     u32x4 v = {(unsigned)lane, (unsigned)wave, 3u, 4u};
+    extern __shared__ char lds[];
+    const char *lsrc = buf + ((size_t)1 << 30) + (size_t)(gwave & 255) * 65536 + lane * 16;
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int r = 0; r < rounds; ++r) {
@@ -32,16 +44,20 @@ __global__ __launch_bounds__(256) void kernel(char *buf, const f16x8 *src, int r
         if (pitch) {
             // (no division here: the walk's arithmetic would sit outside the MFMAs and be what is measured)
             const int j = (r >> 1) & 3, ip = r & 1;
-            pr = buf + ((size_t)(blockIdx.x + 256 * ((r >> 3) & 7)) * 256 + wt * 128 + j * 32 + (lane >> 3)) * pitch + wf * 256 + ip * 128 + (lane & 7) * 16;
+            pr = buf + ((size_t)(blockIdx.x + 256 * ((r >> 3) & 1)) * 256 + wt * 128 + j * 32 + (lane >> 3)) * pitch + wf * 256 + ip * 128 + (lane & 7) * 16;
             row_step = 8 * pitch;
         }
 #pragma unroll
         for (int m = 0; m < 64; ++m) {
             acc[m & 15] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[m & 3], b[(m >> 2) & 3], acc[m & 15], 0, 0, 0);
-            if (NSTORE && m % (64 / (NSTORE ? NSTORE : 1)) == 3) *(u32x4 *)(pr + (m / (64 / (NSTORE ? NSTORE : 1))) * row_step) = v;
+            // PHASED: the loads behind the first NLOAD MFMAs, the stores inside the last 16 — apart in time
+            if (PHASED ? (NLOAD && m < NLOAD) : (NLOAD && m % (64 / (NLOAD ? NLOAD : 1)) == 1))
+                __builtin_amdgcn_global_load_lds(GLOBAL_AS(lsrc + (size_t)((r * 16 + m) & 63) * 1024), LDS_AS(lds + wave * 16384 + (m & 15) * 1024), 16, 0, 0);
+            if (PHASED ? (NSTORE && m >= PHASED && (m - PHASED) % (16 / (NSTORE ? NSTORE : 1)) == 1 && m < PHASED + 16) : (NSTORE && m % (64 / (NSTORE ? NSTORE : 1)) == 3)) *(u32x4 *)(pr + (PHASED ? ((m - PHASED) / (16 / (NSTORE ? NSTORE : 1))) : (m / (64 / (NSTORE ? NSTORE : 1)))) * row_step) = v;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
     for (int i = 0; i < 16; ++i) for (int k = 0; k < 16; ++k) s += acc[i][k];
@@ -58,19 +74,25 @@ int main() {
     srand(1);
     for (auto &x : h) x = (_Float16)((rand() / (float)RAND_MAX - 0.5f) * 0.125f);
     hipMemcpy(src, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+    hipFuncSetAttribute((const void *)kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void *)kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    printf("LDS-DMA pieces per round beside the stores: %d, phased %d\n", NLOAD, PHASED);
     const int rounds = 400;
-    for (size_t pitch : {(size_t)0, (size_t)1536, (size_t)4608, (size_t)6144})
+    for (size_t pitch : {(size_t)4608})
     for (int wrap : {0, 63}) {
         if (pitch && !wrap) continue;
         double base_cyc = 0;
         for (int ns : {0, 1, 2, 4, 8}) {
             for (int rep = 0; rep < 3; ++rep) {
                 switch (ns) {
-                    case 0: hipLaunchKernelGGL(kernel<0>, dim3(256), dim3(256), 0, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
-                    case 1: hipLaunchKernelGGL(kernel<1>, dim3(256), dim3(256), 0, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
-                    case 2: hipLaunchKernelGGL(kernel<2>, dim3(256), dim3(256), 0, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
-                    case 4: hipLaunchKernelGGL(kernel<4>, dim3(256), dim3(256), 0, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
-                    default: hipLaunchKernelGGL(kernel<8>, dim3(256), dim3(256), 0, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
+                    case 0: hipLaunchKernelGGL(kernel<0>, dim3(256), dim3(256), 65536, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
+                    case 1: hipLaunchKernelGGL(kernel<1>, dim3(256), dim3(256), 65536, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
+                    case 2: hipLaunchKernelGGL(kernel<2>, dim3(256), dim3(256), 65536, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
+                    case 4: hipLaunchKernelGGL(kernel<4>, dim3(256), dim3(256), 65536, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
+                    default: hipLaunchKernelGGL(kernel<8>, dim3(256), dim3(256), 65536, 0, buf, src, rounds, (size_t)8192, wrap, pitch, cyc, sink); break;
                 }
                 hipDeviceSynchronize();
             }
