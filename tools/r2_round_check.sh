@@ -16,6 +16,8 @@ timeout 900 python bench.py > $OUT/bench_$TAG.log 2> $OUT/bench_$TAG.err; echo "
 cd /tmp
 B1="python $OUT/../bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_$TAG -o stats -- $B1 > $OUT/bench_prof_$TAG.log 2>&1; echo "stats rc=$?"
+B3="python $OUT/../bench.py --config 3 --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --also"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats3_$TAG -o stats -- $B3 > $OUT/bench_prof3_$TAG.log 2>&1; echo "stats3 rc=$?"
 P1="python $OUT/../bench.py --steps 2 --warmup 1 --repeat 1 --no-cpu-baseline --also"
 i=0
 for set in \
@@ -34,10 +36,15 @@ for cfg in 1 2 22 3; do
 done
 cd $OUT/..
 python tools/rocpd_summary.py stats $(find $OUT/prof_stats_$TAG -name '*_results.db' | head -1) > $OUT/stats_$TAG.txt 2>&1
+python tools/rocpd_summary.py gaps $(find $OUT/prof_stats_$TAG -name '*_results.db' | head -1) >> $OUT/stats_$TAG.txt 2>&1
+python tools/rocpd_summary.py stats $(find $OUT/prof_stats3_$TAG -name '*_results.db' | head -1) > $OUT/stats_config3_$TAG.txt 2>&1
 for j in 1 2; do python tools/rocpd_summary.py pmc $(find $OUT/prof_pmc${j}_$TAG -name '*_results.db' | head -1) > $OUT/pmc${j}_$TAG.txt 2>&1; done
 python tools/rocpd_summary.py pmc $(find $OUT/prof_fetch1_$TAG $OUT/prof_write1_$TAG -name '*_results.db') > $OUT/pmc3_$TAG.txt 2>&1
 python tools/rocpd_summary.py pmc $(find $OUT/prof_fetch3_$TAG $OUT/prof_write3_$TAG -name '*_results.db') > $OUT/pmc3c3_$TAG.txt 2>&1
 python tools/pmc_traffic.py $TR > $OUT/traffic_$TAG.json 2>&1
 grep -h '^{' $OUT/bench_prof_$TAG.log | tail -1 > $OUT/bench_prof_line_$TAG.txt
-rm -rf $OUT/prof_stats_$TAG $OUT/prof_pmc*_$TAG $OUT/prof_fetch*_$TAG $OUT/prof_write*_$TAG
+rm -rf $OUT/prof_stats_$TAG $OUT/prof_stats3_$TAG $OUT/prof_pmc*_$TAG $OUT/prof_fetch*_$TAG $OUT/prof_write*_$TAG
+# calibration lines: the vendor GEMM library on the same shapes and box, the vector-memory microbenchmarks
+timeout 120 python tools/gemm_calibration.py > $OUT/gemm_calibration_$TAG.txt 2>&1; echo "calibration rc=$?"
+(timeout 60 tools/ubench/store_issue; timeout 60 tools/ubench/store_beside_mfma; timeout 60 tools/ubench/store_beside_mfma_l16) > $OUT/store_ubench_$TAG.txt 2>&1; echo "ubench rc=$?"
 head -14 $OUT/stats_$TAG.txt
