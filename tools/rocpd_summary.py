@@ -32,7 +32,8 @@ def gaps(path, same_pass_us=50.0):
     """Time the GPU sits between the end of one kernel and the start of the next inside a forward pass (pairs further apart
     than `same_pass_us` are host-side pauses between timed regions, not launch boundaries)."""
     db = sqlite3.connect(path)
-    rows = sorted(db.execute("select name, start, end from kernels").fetchall(), key=lambda r: r[1])
+    # (runtime copy / fill kernels belong to the benchmark's set-up, not to the forward pass)
+    rows = sorted((r for r in db.execute("select name, start, end from kernels").fetchall() if "__amd_rocclr" not in r[0]), key=lambda r: r[1])
     busy = gap = 0.0
     n = 0
     per = defaultdict(list)
