@@ -50,6 +50,9 @@ constexpr int LT_TILE = 16384;
 #endif
 // LT_BIASINIT: the up-projection accumulators start from the bias of their chunk (written where they used to be
 // zeroed) instead of the bias being added in front of the GELU
+#ifndef LT_DMA_SPREAD
+#define LT_DMA_SPREAD 1
+#endif
 #ifndef LT_BIASINIT
 #define LT_BIASINIT 1
 #endif
@@ -328,10 +331,15 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         read_half(cur, H0{}, so);
         fence(H0{});
         // the 4 DMA pieces go behind MFMAs 1, 3, 5, 7 of the owed half (a piece costs >= 60 issue cycles, an MFMA covers 32)
+        // LT_DMA_SPREAD: behind MFMAs 1 and 5 of the owed half and of this tile's first half instead
         if constexpr (P::kind != K_NONE)
             mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) {
                 constexpr int kk = decltype(k)::value;
-                if constexpr (kk & 1) prefetch(pslot, std::integral_constant<int, (kk >> 1)>{});
+                if constexpr (LT_DMA_SPREAD) {
+                    if constexpr (kk == 1 || kk == 5) prefetch(pslot, std::integral_constant<int, (kk >> 2)>{});
+                } else {
+                    if constexpr (kk & 1) prefetch(pslot, std::integral_constant<int, (kk >> 1)>{});
+                }
                 filler(H0{}, k);
             });
         else prefetch(pslot, ALLP{});
@@ -339,7 +347,11 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         read_half(cur, H1{}, so);
         if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
         fence(H1{});
-        mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) { filler(H1{}, k); });
+        mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) {
+            constexpr int kk = decltype(k)::value;
+            if constexpr (LT_DMA_SPREAD && P::kind != K_NONE && (kk == 1 || kk == 5)) prefetch(pslot, std::integral_constant<int, 2 + (kk >> 2)>{});
+            filler(H1{}, k);
+        });
         // the first-half MFMAs cover the second-half reads; left alone the scheduler sinks them below the barrier, whose
         // lgkmcnt(0) then waits for those reads with an empty matrix pipe
         __builtin_amdgcn_sched_barrier(0);
