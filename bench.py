@@ -27,7 +27,8 @@ Extra objects:
                  built, its arithmetic lives in the un-vendored ggml submodule) timed on this box's
                  host cores over a bounded sample of the same sentences;
   also         — the other single-GPU BASELINE configs (2 as written and with the engine default, 3) and a
-                 real-text-like mixed-length batch, each with its own roofline / cosine / cpu sample.
+                 real-text-like mixed-length batch (ids in HBM, and host to host), each with its own roofline /
+                 cosine / cpu sample.
 """
 import argparse
 import json

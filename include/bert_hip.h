@@ -67,7 +67,9 @@ BERT_API int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vo
  *   - the workspace grows on demand, and growing allocates (synchronises the device, illegal under stream capture):
  *     call bert_hip_reserve once with the largest batch first;
  *   - lengths are validated on the device: a sentence longer than max_len (or empty) yields a NaN embedding and sets a
- *     status word that bert_hip_check returns (and clears) after synchronising.                                      */
+ *     status word that bert_hip_check returns (and clears) after synchronising;
+ *   - short sentences are packed several to a 128-slot attention window by a kernel of the pass itself (the lengths
+ *     exist only in HBM here): results are the bits of the host entry points.                                        */
 BERT_API int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens,
                                              const int32_t *d_cu_seqlens, int32_t n_sentences,
                                              int32_t n_tokens_total, int32_t max_len,
