@@ -34,7 +34,7 @@ namespace {
 constexpr int LT_TILE = 16384;
 
 // LT_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no GELU arithmetic, bit 2 no tile barrier,
-// bit 3 no fragment reads, bit 4 no MFMAs, bit 5 no GELU filler in the last interval of a chunk, bit 6 no GELU filler at all — what a component costs is the time its removal saves (tools/variant.sh)
+// bit 3 no fragment reads, bit 4 no MFMAs, bit 5 no GELU filler in the last interval of a chunk, bit 6 no GELU filler at all, bit 7 no LDS-read waits — what a component costs is the time its removal saves (tools/variant.sh)
 #ifndef LT_ABLATE
 #define LT_ABLATE 0
 #endif
@@ -74,12 +74,18 @@ struct TileDesc {
 };
 using NoTile = TileDesc<K_NONE, 0, 0>;
 
+// (LT_ABLATE bit 7: no wait for LDS reads anywhere — what their exposed latency costs: 1 %)
+#if LT_ABLATE & 128
+#define LT_LGKM(n) "15"
+#else
+#define LT_LGKM(n) #n
+#endif
 __device__ __forceinline__ void wait_lgkm8(f16x8 (&f)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(8)"
+    asm volatile("s_waitcnt lgkmcnt(" LT_LGKM(8) ")"
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory");
 }
 __device__ __forceinline__ void wait_lgkm12(f16x8 (&f)[8], f16x8 (&y)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(12)"
+    asm volatile("s_waitcnt lgkmcnt(" LT_LGKM(12) ")"
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
                    "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : : "memory");
 }
@@ -137,9 +143,9 @@ __device__ __forceinline__ void bias_fence_n(f32x2 (&b)[6]) {
 template <int VM>
 __device__ __forceinline__ void tile_barrier(f16x8 (&f)[8], f16x8 (&y)[4]) {
 #if LT_ABLATE & 4
-#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(0)"
+#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(" LT_LGKM(0) ")"
 #else
-#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(0)\n\ts_barrier"
+#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(" LT_LGKM(0) ")\n\ts_barrier"
 #endif
     asm volatile(LT_BARRIER_TEXT
                  : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
