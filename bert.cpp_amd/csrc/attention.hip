@@ -116,17 +116,21 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[kt], 0, 0, 0);
                 }
             }
-            // ---- mask the ragged tail, chunk max
+            // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
+            if (kc + ATT_CHUNK > n) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        s[kt][r] = key < n ? s[kt][r] : -INFINITY;
+                    }
+            }
             float mx = -INFINITY;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const float v = key < n ? s[kt][r] : -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit; the exponent below is one
             // fma per score (the same arithmetic as qkv_attention.hip / qkv_attention2.hip: equal bits across the kernels)
