@@ -102,20 +102,33 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             for (int r = 0; r < 16; ++r) o[dv][r] = 0.f;
         float m_run = -INFINITY, l_run = 0.f;
 
+        // fragment addresses of the chunk at kc = 0: the swizzle of a K row depends on the row's low bits, i.e. on l31 only,
+        // and a V^T row's keys are consecutive, so inside the chunk loop every read is base + compile-time offset and a
+        // chunk step is one addition per base (left to the compiler this was ~100 address instructions per chunk)
+        typedef const __attribute__((address_space(3))) char *lds_bytes;       // (typed LDS pointers: generic ones become flat loads)
+        typedef const __attribute__((address_space(3))) half_t *lds_halfs;
+        lds_bytes kbase[D / 16];
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) kbase[kk] = (lds_bytes)Ks + k_off<D>(l31, kk * 2 + hi);
+        lds_halfs vbase[D / 32];
+#pragma unroll
+        for (int dv = 0; dv < D / 32; ++dv) vbase[dv] = (lds_halfs)Vt + (dv * 32 + l31) * vt_ld + 4 * hi;
+        constexpr int K_ROW = D * 2;                   // bytes per K row
+
         for (int kc = 0; kc < n_pad; kc += ATT_CHUNK) {
             // ---- S^T chunk: 4 key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
             f32x16 s[4];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-                const int krow = kc + kt * 32 + l31;
-#pragma unroll
                 for (int kk = 0; kk < D / 16; ++kk) {
-                    const f16x8 kf = *(const f16x8 *)(Ks + k_off<D>(krow, kk * 2 + hi));
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[kt], 0, 0, 0);
+                    const f16x8 kf = *(const __attribute__((address_space(3))) f16x8 *)(kbase[kk] + kt * 32 * K_ROW);
+                    // (the first k-step starts from the constant 0: no zeroing moves)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
                 }
             }
+#pragma unroll
+            for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += ATT_CHUNK * K_ROW;
             // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
             if (kc + ATT_CHUNK > n) {
 #pragma unroll
@@ -160,17 +173,19 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     f16x8 pf;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[e] = (_Float16)s[kt][8 * st + e];
-                    const int key0 = kc + kt * 32 + 16 * st + 4 * hi;     // keys key0..+3 and key0+8..+11
+                    // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
 #pragma unroll
                     for (int dv = 0; dv < D / 32; ++dv) {
-                        const half_t *vr = Vt + (dv * 32 + l31) * vt_ld + key0;
-                        const f16x4 v0 = *(const f16x4 *)vr, v1 = *(const f16x4 *)(vr + 8);
+                        const lds_halfs vr = vbase[dv] + kt * 32 + 16 * st;
+                        const f16x4 v0 = *(const __attribute__((address_space(3))) f16x4 *)vr, v1 = *(const __attribute__((address_space(3))) f16x4 *)(vr + 8);
                         f16x8 vf;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
                         o[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dv], 0, 0, 0);
                     }
                 }
+#pragma unroll
+            for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += ATT_CHUNK;
         }
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
         const int q = qb * 32 + l31;
