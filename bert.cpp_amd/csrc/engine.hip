@@ -159,6 +159,33 @@ bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool wa
 // ------------------------------------------------------------------------------------------------
 static bool upload_f32(DevBuf &b, const HostTensor *t, std::string &err) { return b.upload(t->data, t->nbytes, err); }
 
+// an embedding table of a q4 file as f32 values: (q - 8) d / q d + m, the numbers the gather kernel dequantises on the fly
+// (q d is exact in f32, so the host's multiply-add and the device's fma round alike); 6.4x the bytes, but the f32 form is
+// read by the 16-byte-run kernel (embed_ln_rows_kernel) instead of element by element
+static bool upload_table_f32(DevBuf &b, const HostTensor *t, std::string &err) {
+    const int64_t K = t->ne0, N = t->ne1;
+    const int bs = t->type == W_Q4_0 ? 18 : 20;
+    std::vector<float> img((size_t)N * K);
+    for (int64_t r = 0; r < N; ++r) {
+        const uint8_t *src = t->data + wtype_row_bytes(t->type, K) * (size_t)r;
+        float *dst = img.data() + (size_t)r * K;
+        for (int64_t blk_i = 0; blk_i < K / 32; ++blk_i) {
+            const uint8_t *blk = src + blk_i * bs;
+            uint16_t dbits; memcpy(&dbits, blk, 2);
+            const float d = h2f(dbits);
+            float m = 0.f;
+            const uint8_t *qs = blk + 2;
+            if (t->type == W_Q4_1) { uint16_t mb; memcpy(&mb, blk + 2, 2); m = h2f(mb); qs = blk + 4; }
+            for (int j = 0; j < 16; ++j) {
+                const int q0 = qs[j] & 0x0F, q1 = qs[j] >> 4;
+                dst[blk_i * 32 + j] = t->type == W_Q4_0 ? (float)(q0 - 8) * d : (float)q0 * d + m;
+                dst[blk_i * 32 + j + 16] = t->type == W_Q4_0 ? (float)(q1 - 8) * d : (float)q1 * d + m;
+            }
+        }
+    }
+    return b.upload(img.data(), img.size() * sizeof(float), err);
+}
+
 static bool concat_upload(DevBuf &b, std::initializer_list<const HostTensor *> ts, std::string &err) {
     std::vector<uint8_t> all;
     for (auto *t : ts) all.insert(all.end(), t->data, t->data + t->nbytes);
@@ -198,9 +225,17 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     auto T = [&](const std::string &n) { return mf.find(n); };
     bool ok = true;
     e->table_type_ = mf.hp.f16;
-    ok = ok && upload_f32(e->word_emb_, T("embeddings.word_embeddings.weight"), err);
-    ok = ok && upload_f32(e->type_emb_, T("embeddings.token_type_embeddings.weight"), err);
-    ok = ok && upload_f32(e->pos_emb_, T("embeddings.position_embeddings.weight"), err);
+    {
+        const HostTensor *tw = T("embeddings.word_embeddings.weight"), *tt = T("embeddings.token_type_embeddings.weight"),
+                         *tp = T("embeddings.position_embeddings.weight");
+        const bool q4_tables = tw && tt && tp && (tw->type == W_Q4_0 || tw->type == W_Q4_1) && tt->type == tw->type && tp->type == tw->type;
+        if (q4_tables && e->q4_expand_ && mf.hp.n_embd % 32 == 0) {
+            e->table_type_ = 0;
+            ok = ok && upload_table_f32(e->word_emb_, tw, err) && upload_table_f32(e->type_emb_, tt, err) && upload_table_f32(e->pos_emb_, tp, err);
+        } else {
+            ok = ok && upload_f32(e->word_emb_, tw, err) && upload_f32(e->type_emb_, tt, err) && upload_f32(e->pos_emb_, tp, err);
+        }
+    }
     ok = ok && upload_f32(e->ln_e_w_, T("embeddings.LayerNorm.weight"), err);
     ok = ok && upload_f32(e->ln_e_b_, T("embeddings.LayerNorm.bias"), err);
     const bool want_naive = e->gemm_naive_;
