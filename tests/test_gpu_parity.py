@@ -144,8 +144,8 @@ def test_ffn_block_kernel(fused, ftype, M, H, I):
     assert err.mean() < 2.5e-3
 
 
-@pytest.mark.parametrize("impl", [1, 2], ids=["token-owning", "panel"])
-@pytest.mark.parametrize("M,H,I", [(200, 128, 256), (256, 256, 512), (130, 384, 1536), (384, 384, 256), (128, 128, 128)])
+@pytest.mark.parametrize("impl", [1, 2, 3], ids=["token-owning", "panel", "wave-pairs"])
+@pytest.mark.parametrize("M,H,I", [(200, 128, 256), (256, 256, 512), (130, 384, 1536), (384, 384, 256), (128, 128, 128), (1000, 256, 1024)])
 def test_layer_tail_kernel(impl, M, H, I):
     """Out-projection + LN + FFN + LN in one launch (layer_tail.hip / ffn_fused.hip) against a float64 reference of
     reference bert.cpp:859-901 and against the five-kernel path."""
