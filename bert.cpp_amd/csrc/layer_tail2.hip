@@ -30,7 +30,7 @@ namespace {
 
 constexpr int L2_TILE = 16384;
 // L2_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no s_barrier, bit 2 no fragment reads, bit 3 no
-// MFMAs, bit 4 no partial / GELU exchange — what a component costs is the time its removal saves (tools/variant.sh)
+// MFMAs, bit 4 no partial / GELU exchange, bit 5 no GELU arithmetic (the exchange stays) — what a component costs is the time its removal saves (tools/variant.sh)
 #ifndef L2_ABLATE
 #define L2_ABLATE 0
 #endif
@@ -321,21 +321,26 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     };
     constexpr int FILL_IVS = 2 * (NT - 1), SPI = 8 / FILL_IVS;           // filler intervals per chunk, GELU pairs per interval
     static_assert(SPI * FILL_IVS == 8 && SPI <= 4, "two or four pairs per filler interval");
-    // pair k of the interval's SPI pairs behind k-step kk: spread over the tile's four k-steps
-    auto gelu_filler = [&](auto iv_tag) __attribute__((always_inline)) {
+    // pair k of the interval's SPI pairs behind k-step kk: spread over the tile's four k-steps.  ABSORB: the interval also
+    // takes the partial sums in (behind k-step 0) and its pairs follow one k-step later
+    auto gelu_filler = [&](auto iv_tag, auto absorb_tag) __attribute__((always_inline)) {
         return [&](int kk) __attribute__((always_inline)) {
             constexpr int iv = decltype(iv_tag)::value;
+            constexpr bool ABSORB = decltype(absorb_tag)::value;
             if (L2_ABLATE & 16) return;
+            if (ABSORB && kk == 0) absorb();
 #pragma unroll
             for (int k = 0; k < SPI; ++k)
-                if (kk == k * (4 / SPI)) pre[iv * SPI + k] = gelu_pk16h(pre[iv * SPI + k]);
+                if (kk == (SPI == 4 ? k : 2 * k + (ABSORB ? 1 : 0)) && !(L2_ABLATE & 32) && !(ABSORB && SPI == 4 && k == 0))
+                    pre[iv * SPI + k] = gelu_pk16h(pre[iv * SPI + k]);
+            if (ABSORB && SPI == 4 && kk == 3 && !(L2_ABLATE & 32)) pre[iv * SPI] = gelu_pk16h(pre[iv * SPI]);     // (NT = 2: pair 0 waits for the sums too)
         };
     };
     auto gelu_range = [&](int first, int last) __attribute__((always_inline)) {     // pairs first .. last - 1 at once (first / last chunk)
         if (L2_ABLATE & 16) return;
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k >= first && k < last) pre[k] = gelu_pk16h(pre[k]);
+            if (k >= first && k < last && !(L2_ABLATE & 32)) pre[k] = gelu_pk16h(pre[k]);
     };
     auto publish = [&]() __attribute__((always_inline)) {
         if (L2_ABLATE & 16) return;
@@ -358,9 +363,10 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     };
 
     // stream order: UP(0) | UP(1) | DOWN(0) | UP(2) | DOWN(1) | ... | UP(NC-1) | DOWN(NC-2) | DOWN(NC-1), NT tiles each.
-    // Life of chunk c: partial sums in UP(c) -> sent before the barrier of its last tile -> absorbed behind DOWN(c-1)'s first
-    // tile -> GELU pairs behind DOWN(c-1)'s other tiles and UP(c+1)'s first NT-1 tiles -> published before the barrier of
-    // UP(c+1)'s last tile -> fetched by both waves of the pair behind it -> multiplied in DOWN(c).
+    // Life of chunk c: partial sums in UP(c) -> sent behind the first MFMAs of DOWN(c-1)'s first tile -> taken in behind its
+    // second tile -> GELU pairs behind that and the following tiles up to UP(c+1)'s last but one -> published behind the first
+    // MFMAs of UP(c+1)'s last tile -> fetched by both waves of the pair behind its barrier -> multiplied in DOWN(c).
+    // (Every piece rides between MFMAs: whatever a wave does between its last MFMA and a barrier keeps seven waves waiting.)
     // ---- UP(0)  (its first two tiles were requested by the last out-projection intervals)
     static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
         constexpr int j = decltype(j_tag)::value, j2 = j + 2;
@@ -381,9 +387,8 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             auto pf = [&](int s2) __attribute__((always_inline)) {
                 if constexpr (j2 < NT) dma_up(c + 1, j2, s2); else dma_down(c, j2 - NT, s2);
             };
-            if constexpr (j < NT - 1) up_tile(j_tag, c + 1, pf, gelu_filler(std::integral_constant<int, (NT - 1) + j>{}));   // chunk c's last pairs
-            else up_tile(j_tag, c + 1, pf, no_filler);
-            if constexpr (j == NT - 1) { publish(); send_partial(); }
+            if constexpr (j < NT - 1) up_tile(j_tag, c + 1, pf, gelu_filler(std::integral_constant<int, (NT - 1) + j>{}, std::false_type{}));   // chunk c's last pairs
+            else up_tile(j_tag, c + 1, pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) publish(); });                           // chunk c goes to G
             close(VM2{});
         });
         fetch_chunk();                                        // chunk c: both halves were published before the last barrier
@@ -394,12 +399,11 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
                 else if constexpr (!LAST) dma_up(c + 2, d2 - NT, s2);
                 else dma_down(c + 1, d2 - NT, s2);            // chunk c+1 is the last one: only its DOWN tiles are left
             };
-            if constexpr (d == 0) {
-                rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, no_filler);
-                absorb();
-            } else {
-                rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 1>{}));            // chunk c+1's first pairs
-            }
+            // chunk c+1: its partial sums cross to the partner behind tile 0 (they have been final since the last barrier),
+            // are taken in behind tile 1, the first GELU pairs follow
+            if constexpr (d == 0) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) send_partial(); });
+            else if constexpr (d == 1) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, 0>{}, std::true_type{}));
+            else rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 1>{}, std::false_type{}));
             close(VM2{});
         });
     };

@@ -607,7 +607,8 @@ def test_legacy_q4_files_load_and_give_the_same_embeddings(tmp_path, ftype):
     assert np.array_equal(pybert.BertModel(cur).eval_batch(sents), pybert.BertModel(leg).eval_batch(sents))
 
 
-@pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL", "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
+@pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_TAIL=2", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL",
+                                  "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
 def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
     """The fused kernels each have a fallback family (token-owning layer tail -> 128-token panel kernels -> tiled GEMMs
     + LayerNorm kernels; fused projection+attention -> QKV GEMM + attention kernel).  On the benchmark's dimensions
@@ -617,10 +618,14 @@ def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
     sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (128, 128, 96, 128, 77, 128)]
     base = pybert.BertModel(path).eval_batch(sents)
     for k in knob.split("+"):
-        monkeypatch.setenv(k, "0")
-    alt = pybert.BertModel(path).eval_batch(sents)
+        monkeypatch.setenv(k.split("=")[0], k.split("=")[1] if "=" in k else "0")      # ("=2": the wave-pair layer tail, layer_tail2.hip)
+    m_alt = pybert.BertModel(path)
+    alt = m_alt.eval_batch(sents)
+    if knob == "BERT_HIP_TAIL=2":
+        m_alt.profile(True); m_alt.eval_batch(sents); names = set(m_alt.profile_report()); m_alt.profile(False)
+        assert "layer_tail2" in names and "layer_tail" not in names, names
     for k in knob.split("+"):
-        monkeypatch.delenv(k)
+        monkeypatch.delenv(k.split("=")[0])
     want = orc.Oracle(path).eval(sents[2])
     assert cosine(base[2], want) > 1 - 1e-4 and cosine(alt[2], want) > 1 - 1e-4
     for i in range(len(sents)):
