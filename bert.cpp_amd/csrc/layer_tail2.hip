@@ -30,7 +30,8 @@ namespace {
 
 constexpr int L2_TILE = 16384;
 // L2_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no s_barrier, bit 2 no fragment reads, bit 3 no
-// MFMAs, bit 4 no partial / GELU exchange, bit 5 no GELU arithmetic (the exchange stays) — what a component costs is the time its removal saves (tools/variant.sh)
+// MFMAs, bit 4 no partial / GELU exchange, bit 5 no GELU arithmetic (the exchange stays),
+// bit 6 no send_partial, bit 7 no absorb, bit 8 no publish, bit 9 no fetch_chunk — what a component costs is the time its removal saves (tools/variant.sh)
 #ifndef L2_ABLATE
 #define L2_ABLATE 0
 #endif
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     };
     // the partial sums of the chunk half the partner finishes go to X (before a barrier)
     auto send_partial = [&]() __attribute__((always_inline)) {
-        if (L2_ABLATE & 16) return;
+        if (L2_ABLATE & (16 | 64)) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 v;
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) pre[k] = f16x2_t{(_Float16)0.f, (_Float16)0.f};
     auto absorb = [&]() __attribute__((always_inline)) {
-        if (L2_ABLATE & 16) return;
+        if (L2_ABLATE & (16 | 128)) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 pv = *(const f32x4 *)(Xp + q * 1024);
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             if (k >= first && k < last && !(L2_ABLATE & 32)) pre[k] = gelu_pk16h(pre[k]);
     };
     auto publish = [&]() __attribute__((always_inline)) {
-        if (L2_ABLATE & 16) return;
+        if (L2_ABLATE & (16 | 256)) return;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             f16x8 o;
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     // both halves of the GELU'ed chunk from G (behind a barrier): g[0..1] = the half this wave made, g[2..3] = the partner's
     // (the down-projection's fragment addresses visit the weight k-steps in that order)
     auto fetch_chunk = [&]() __attribute__((always_inline)) {
+        if (L2_ABLATE & 512) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             g[s] = *(const f16x8 *)(Gw + s * 1024);
