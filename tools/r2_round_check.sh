@@ -5,6 +5,7 @@
 #   with trace domains other than --kernel-trace).
 # usage (from the repo root on the GPU box):  bash tools/r2_round_check.sh [tag]
 set -u
+trap '' PIPE        # (a reader that stops early — `| head` — must not end the run half way)
 TAG=${1:-r2}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
