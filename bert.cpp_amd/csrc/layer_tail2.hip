@@ -311,30 +311,33 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     f16x2_t pre[8];                                           // pairs 2 q, 2 q + 1 = registers 4 q .. 4 q + 3 of the half
 #pragma unroll
     for (int k = 0; k < 8; ++k) pre[k] = f16x2_t{(_Float16)0.f, (_Float16)0.f};
-    auto absorb = [&]() __attribute__((always_inline)) {
+    f32x4 xin[4];                                             // the partner's partial sums on their way in
+    auto absorb_load = [&]() __attribute__((always_inline)) {
+        if (L2_ABLATE & (16 | 128)) return;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xin[q] = *(const f32x4 *)(Xp + q * 1024);      // four reads in flight together
+    };
+    auto absorb_math = [&]() __attribute__((always_inline)) {
         if (L2_ABLATE & (16 | 128)) return;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 pv = *(const f32x4 *)(Xp + q * 1024);
-            pre[2 * q] = f16x2_t{(_Float16)(accU[0][4 * q] + pv[0]), (_Float16)(accU[0][4 * q + 1] + pv[1])};
-            pre[2 * q + 1] = f16x2_t{(_Float16)(accU[0][4 * q + 2] + pv[2]), (_Float16)(accU[0][4 * q + 3] + pv[3])};
+            pre[2 * q] = f16x2_t{(_Float16)(accU[0][4 * q] + xin[q][0]), (_Float16)(accU[0][4 * q + 1] + xin[q][1])};
+            pre[2 * q + 1] = f16x2_t{(_Float16)(accU[0][4 * q + 2] + xin[q][2]), (_Float16)(accU[0][4 * q + 3] + xin[q][3])};
         }
     };
-    constexpr int FILL_IVS = 2 * (NT - 1), SPI = 8 / FILL_IVS;           // filler intervals per chunk, GELU pairs per interval
-    static_assert(SPI * FILL_IVS == 8 && SPI <= 4, "two or four pairs per filler interval");
-    // pair k of the interval's SPI pairs behind k-step kk: spread over the tile's four k-steps.  ABSORB: the interval also
-    // takes the partial sums in (behind k-step 0) and its pairs follow one k-step later
-    auto gelu_filler = [&](auto iv_tag, auto absorb_tag) __attribute__((always_inline)) {
+    auto absorb = [&]() __attribute__((always_inline)) { absorb_load(); absorb_math(); };
+    // the 8 GELU pairs of a half chunk ride in NG tile intervals: DOWN tiles 2 .. NT-1 of the previous chunk (NT - 2 of them),
+    // then UP tiles 0 .. NT-2 of the next one; interval gi carries pairs gstart(gi) .. gstart(gi + 1) - 1
+    constexpr int NG = 2 * NT - 3;
+    auto gstart = [](int gi) constexpr { return (8 * gi + NG - 1) / NG; };
+    static_assert(NG >= 1, "");
+    auto gelu_filler = [&](auto gi_tag) __attribute__((always_inline)) {
         return [&](int kk) __attribute__((always_inline)) {
-            constexpr int iv = decltype(iv_tag)::value;
-            constexpr bool ABSORB = decltype(absorb_tag)::value;
-            if (L2_ABLATE & 16) return;
-            if (ABSORB && kk == 0) absorb();
+            constexpr int gi = decltype(gi_tag)::value, p0 = (8 * gi + NG - 1) / NG, p1 = (8 * (gi + 1) + NG - 1) / NG, np = p1 - p0;
+            if ((L2_ABLATE & 16) || (L2_ABLATE & 32)) return;
 #pragma unroll
-            for (int k = 0; k < SPI; ++k)
-                if (kk == (SPI == 4 ? k : 2 * k + (ABSORB ? 1 : 0)) && !(L2_ABLATE & 32) && !(ABSORB && SPI == 4 && k == 0))
-                    pre[iv * SPI + k] = gelu_pk16h(pre[iv * SPI + k]);
-            if (ABSORB && SPI == 4 && kk == 3 && !(L2_ABLATE & 32)) pre[iv * SPI] = gelu_pk16h(pre[iv * SPI]);     // (NT = 2: pair 0 waits for the sums too)
+            for (int k = 0; k < np; ++k)
+                if (kk == (np <= 4 ? k : k / 2)) pre[p0 + k] = gelu_pk16h(pre[p0 + k]);
         };
     };
     auto gelu_range = [&](int first, int last) __attribute__((always_inline)) {     // pairs first .. last - 1 at once (first / last chunk)
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
 
     // stream order: UP(0) | UP(1) | DOWN(0) | UP(2) | DOWN(1) | ... | UP(NC-1) | DOWN(NC-2) | DOWN(NC-1), NT tiles each.
     // Life of chunk c: partial sums in UP(c) -> sent behind the first MFMAs of DOWN(c-1)'s first tile -> taken in behind its
-    // second tile -> GELU pairs behind that and the following tiles up to UP(c+1)'s last but one -> published behind the first
+    // second tile -> GELU pairs behind the following tiles up to UP(c+1)'s last but one -> published behind the first
     // MFMAs of UP(c+1)'s last tile -> fetched by both waves of the pair behind its barrier -> multiplied in DOWN(c).
     // (Every piece rides between MFMAs: whatever a wave does between its last MFMA and a barrier keeps seven waves waiting.)
     // ---- UP(0)  (its first two tiles were requested by the last out-projection intervals)
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         close(VM2{});
     });
     absorb();
-    gelu_range(0, (NT - 1) * SPI);                            // (what DOWN(-1)'s tiles would have carried)
+    gelu_range(0, gstart(NT - 2));                            // (what DOWN(-1)'s tiles would have carried)
 
     // ---- step c: UP(c+1), then DOWN(c)
     auto step = [&](int c, auto last_tag) __attribute__((always_inline)) {
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             auto pf = [&](int s2) __attribute__((always_inline)) {
                 if constexpr (j2 < NT) dma_up(c + 1, j2, s2); else dma_down(c, j2 - NT, s2);
             };
-            if constexpr (j < NT - 1) up_tile(j_tag, c + 1, pf, gelu_filler(std::integral_constant<int, (NT - 1) + j>{}, std::false_type{}));   // chunk c's last pairs
+            if constexpr (j < NT - 1) up_tile(j_tag, c + 1, pf, gelu_filler(std::integral_constant<int, (NT - 2) + j>{}));   // chunk c's last pairs
             else up_tile(j_tag, c + 1, pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) publish(); });                           // chunk c goes to G
             close(VM2{});
         });
@@ -404,15 +407,18 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             // chunk c+1: its partial sums cross to the partner behind tile 0 (they have been final since the last barrier),
             // are taken in behind tile 1, the first GELU pairs follow
             if constexpr (d == 0) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) send_partial(); });
-            else if constexpr (d == 1) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, 0>{}, std::true_type{}));
-            else rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 1>{}, std::false_type{}));
+            else if constexpr (d == 1) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) {
+                if (kk == 2) absorb_load();               // (the first fragments of the tile are spent: their registers carry the sums)
+                if (kk == 3) absorb_math();
+            });
+            else rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 2>{}));
             close(VM2{});
         });
     };
     for (int c = 0; c + 2 < NC; ++c) step(c, std::false_type{});
     step(NC - 2, std::true_type{});
     // ---- DOWN(NC-1): the rest of its GELU at once
-    gelu_range((NT - 1) * SPI, 8);
+    gelu_range(gstart(NT - 2), 8);
     publish();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     fetch_chunk();
