@@ -35,6 +35,10 @@ constexpr int L2_TILE = 16384;
 #ifndef L2_ABLATE
 #define L2_ABLATE 0
 #endif
+// L2_DMA_LATE: 1 = a tile interval requests tile +2 behind its fragment reads instead of in front of them
+#ifndef L2_DMA_LATE
+#define L2_DMA_LATE 1
+#endif
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -159,8 +163,8 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         // [128 x 64] tile: acc2[n3*2 + obp] += W(row block 2 fh + obp, k-step kk) x b[kk]
         constexpr int n3 = decltype(n3_tag)::value;
         const unsigned so = (unsigned)slot * L2_TILE;
-        prefetch(slot == 0 ? 2 : slot - 1);
         const f16x8 bq[4] = {b0, b1, b2, b3};
+        if (!L2_DMA_LATE) prefetch(slot == 0 ? 2 : slot - 1);
         unsigned ab = base + so;                              // (opaque: the four k-step addresses are XORs made here, not kept)
         asm volatile("" : "+v"(ab));
         f16x8 F[4][2];
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             F[kk][1] = frag((ab ^ (unsigned)(kk << 5)) + 4096);
         }
         __builtin_amdgcn_sched_barrier(0);                    // every fragment of the tile is requested before the first MFMA
+        if (L2_DMA_LATE) prefetch(slot == 0 ? 2 : slot - 1);  // the requests for tile +2 behind the reads: they have two intervals to land
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (L2_ABLATE & 8) { asm volatile("" : "+v"(acc2[n3 * 2][0]), "+v"(acc2[n3 * 2 + 1][0]) : "v"(F[kk][0]), "v"(F[kk][1]), "v"(bq[kk])); continue; }
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         // [64 x 128] tile j: accU[0] (the row block this wave finishes) and accU[1] (the partner's) += W1(rows, k-step 4 fh + kk) x yf[4 j + kk]
         constexpr int j = decltype(j_tag)::value;
         const unsigned so = (unsigned)slot * L2_TILE;
-        prefetch(slot == 0 ? 2 : slot - 1);
+        if (!L2_DMA_LATE) prefetch(slot == 0 ? 2 : slot - 1);
         unsigned ab = aU + so;
         int uoo = uo;
         asm volatile("" : "+v"(ab), "+v"(uoo));
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (L2_DMA_LATE) prefetch(slot == 0 ? 2 : slot - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             if (L2_ABLATE & 8) { asm volatile("" : "+v"(accU[0][0]), "+v"(accU[1][0]) : "v"(F[kk][0]), "v"(F[kk][1]), "v"(yf[4 * j + kk])); continue; }
