@@ -21,7 +21,10 @@
 //   * the residual inputs are the accumulators' initial values (x + bo before the out-projection, y + b2 before the
 //     feed-forward), so neither x nor y is staged in LDS.
 // Everything that crosses between the waves of a pair is written before one of the per-tile workgroup barriers and read
-// behind it.  The weight-tile stream (3-slot ring, two tiles ahead, one barrier per tile) is layer_tail.hip's.
+// behind it, and every piece of that exchange rides between MFMAs (what a wave does between its last MFMA and a barrier keeps
+// seven waves waiting).  The weight-tile stream (3-slot ring, two tiles ahead, one barrier per tile) is layer_tail.hip's.
+// Status (round 2): selected with BERT_HIP_TAIL=2, level with layer_tail.hip (+-2 % per launch); without the pair exchange it
+// runs 25-30 % below it (L2_ABLATE) — the exchange path is what is left to shorten.
 #include "tile_stream.h"
 
 namespace bert_hip {
