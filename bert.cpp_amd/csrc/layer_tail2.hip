@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     auto gelu_filler = [&](auto gi_tag) __attribute__((always_inline)) {
         return [&](int kk) __attribute__((always_inline)) {
             constexpr int gi = decltype(gi_tag)::value, p0 = (8 * gi + NG - 1) / NG, p1 = (8 * (gi + 1) + NG - 1) / NG, np = p1 - p0;
-            if ((L2_ABLATE & 16) || (L2_ABLATE & 32)) return;
+            if (L2_ABLATE & (16 | 32)) return;
 #pragma unroll
             for (int k = 0; k < np; ++k)
                 if (kk == (np <= 4 ? k : k / 2)) pre[p0 + k] = gelu_pk16h(pre[p0 + k]);
