@@ -187,8 +187,11 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         }
     };
     auto no_filler = [](int) __attribute__((always_inline)) {};
+    [[maybe_unused]] int tl = 1;                              // (BERT_HIP_TIMELINE builds: one stamp per tile interval, `make timeline`)
+    TL_STAMP(0);
     auto close = [&](auto vm_tag) __attribute__((always_inline)) {
         l2_barrier<decltype(vm_tag)::value>();
+        TL_STAMP(tl++);
         slot = slot == 2 ? 0 : slot + 1;
     };
     using VM2 = std::integral_constant<int, 2>;
@@ -497,6 +500,7 @@ void launch_layer_tail2(const GemmWeight &Wo, const GemmWeight &W1, const GemmWe
         if (first_launch_on_device(configured[nt]))
             (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
+        TL_DUMP(M_pad >= 128 * 256, 200);
     };
     if (H == 256) go(layer_tail2_kernel<2>, 2); else go(layer_tail2_kernel<3>, 3);
 }
