@@ -426,7 +426,10 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, s); });
             d_windows = windows_.as<int2>();
             d_n_windows = count;
-            n_windows = std::min(uniform, qkv_attention2_max_windows(B, T));   // next-fit never needs more windows than the uniform rule
+            // upper bound from T and B alone (the extra workgroups return at once): "never more than the uniform rule" only
+            // holds for batches that keep their max_len promise, and a broken promise must cost the offender its row, not
+            // a neighbour its window
+            n_windows = qkv_attention2_max_windows(B, T);
         }
     }
     for (int il = 0; il < hp_.n_layer; ++il) {
