@@ -30,7 +30,7 @@ BERT_HIP_H_SYMBOLS = [
 BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
-    "bert_hip_test_build_windows_device",
+    "bert_hip_test_build_windows_device", "bert_hip_test_max_windows",
     "bert_hip_test_dispatch", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
     "bert_hip_test_model_digest",
 ]
@@ -127,6 +127,8 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_shard_bounds.argtypes = [i32p, i32, i32, i32p]
     L.bert_hip_test_build_windows.restype = i32
     L.bert_hip_test_build_windows.argtypes = [i32p, i32, i32p]
+    L.bert_hip_test_max_windows.restype = i32
+    L.bert_hip_test_max_windows.argtypes = [i32, i32]
     L.bert_hip_test_build_windows_device.restype = i32
     L.bert_hip_test_build_windows_device.argtypes = [i32p, i32, i32p]
     L.bert_hip_test_dispatch.restype = i32
@@ -184,6 +186,10 @@ def build_windows(cu_seqlens: np.ndarray, device: bool = False) -> List[tuple]:
     if n < 0:
         raise RuntimeError("bert_hip_test_build_windows_device failed")
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+def max_windows(n_sentences: int, n_tokens: int) -> int:
+    return int(test_lib().bert_hip_test_max_windows(n_sentences, n_tokens))
 
 
 def dispatch_stub(tokens: np.ndarray, cu_seqlens: np.ndarray, n_shards: int, H: int = 4) -> np.ndarray:

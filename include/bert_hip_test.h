@@ -79,6 +79,9 @@ BERT_API int32_t bert_hip_test_model_digest(const char *fname, int32_t *legacy_q
  * (engine.h build_windows; returns their number, `windows` holds 2 ints per window, capacity n_sentences).        */
 BERT_API void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards, int32_t *bounds);
 BERT_API int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows);
+/* Upper bound of the number of windows used to size the grid of the fused attention kernel when the windows are built on the
+ * device (a function of the sentence and token counts only).                                                             */
+BERT_API int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens);
 /* The same windows from the device-side builder the asynchronous device API uses (needs a GPU; -1 on a HIP error).        */
 BERT_API int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows);
 /* The multi-device dispatcher (shard, one thread per shard, results straight into the caller's rows) driven with a stub

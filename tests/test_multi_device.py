@@ -56,6 +56,21 @@ def test_windows_hold_whole_sentences_in_order_and_fit():
     assert pybert.build_windows(_cu([16] * 8 + [1])) == [(0, 8), (8, 1)]
 
 
+def test_the_grid_bound_of_device_built_windows_covers_every_packing():
+    """The device API launches the fused attention kernel before it knows how many windows its own builder kernel makes: the
+    grid is an upper bound computed from the sentence and token counts alone (two neighbouring next-fit windows hold more
+    than 128 slots together).  It must cover the real count whatever the lengths are."""
+    rng = np.random.default_rng(7)
+    for trial in range(300):
+        n = int(rng.integers(1, 400))
+        kind = trial % 4
+        lens = (rng.integers(1, 129, n) if kind == 0 else rng.integers(1, 18, n) if kind == 1 else
+                rng.choice([1, 15, 16, 17, 63, 64, 65, 112, 113, 128], n) if kind == 2 else
+                np.clip(np.round(rng.lognormal(np.log(21.0), 0.7, n)), 1, 128).astype(int))
+        cu = _cu([int(x) for x in lens])
+        assert len(pybert.build_windows(cu)) <= pybert.max_windows(n, int(cu[-1])) <= n, (trial, n)
+
+
 @pytest.mark.parametrize("n_shards", [1, 2, 3, 8])
 def test_dispatcher_with_a_stub_evaluator(n_shards):
     """The code path of a multi-GPU bert_eval_batch (shard, one thread per shard, every shard writes the caller's rows)
