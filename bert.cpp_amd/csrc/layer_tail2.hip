@@ -39,6 +39,11 @@ constexpr int L2_TILE = 16384;
 #define L2_ABLATE 0
 #endif
 // L2_DMA_LATE: 1 = a tile interval requests tile +2 behind its fragment reads instead of in front of them
+// L2_ABSORB_EARLY: 1 = the partner's partial sums are requested in front of the tile's fragment reads (one LDS round trip
+// for both) and added behind its second k-step, 0 = requested behind the third k-step
+#ifndef L2_ABSORB_EARLY
+#define L2_ABSORB_EARLY 1
+#endif
 #ifndef L2_DMA_LATE
 #define L2_DMA_LATE 1
 #endif
@@ -162,12 +167,13 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
     int slot = 0;
     // one tile interval: request tile +2 into the slot freed by the last barrier, multiply this tile, close
     auto rows_tile = [&](unsigned base, auto n3_tag, const f16x8 &b0, const f16x8 &b1, const f16x8 &b2, const f16x8 &b3, auto &&prefetch,
-                         auto &&filler) __attribute__((always_inline)) {
+                         auto &&filler, auto &&early) __attribute__((always_inline)) {
         // [128 x 64] tile: acc2[n3*2 + obp] += W(row block 2 fh + obp, k-step kk) x b[kk]
         constexpr int n3 = decltype(n3_tag)::value;
         const unsigned so = (unsigned)slot * L2_TILE;
         const f16x8 bq[4] = {b0, b1, b2, b3};
         if (!L2_DMA_LATE) prefetch(slot == 0 ? 2 : slot - 1);
+        early();                                              // LDS reads of the pair exchange: in front of the fragment reads, one shared round trip
         unsigned ab = base + so;                              // (opaque: the four k-step addresses are XORs made here, not kept)
         asm volatile("" : "+v"(ab));
         f16x8 F[4][2];
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         }
     };
     auto no_filler = [](int) __attribute__((always_inline)) {};
+    auto no_early = []() __attribute__((always_inline)) {};
     [[maybe_unused]] int tl = 1;                              // (BERT_HIP_TIMELINE builds: one stamp per tile interval, `make timeline`)
     TL_STAMP(0);
     auto close = [&](auto vm_tag) __attribute__((always_inline)) {
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         rows_tile(aA, std::integral_constant<int, n3>{}, bf[4 * kt], bf[4 * kt + 1], bf[4 * kt + 2], bf[4 * kt + 3], [&](int s2) __attribute__((always_inline)) {
             if constexpr (t2 < NT * KU) dma_proj(t2 / KU, t2 % KU, s2);
             else dma_up(0, t2 - NT * KU, s2);                 // the first up-projection tiles of chunk 0
-        }, no_filler);
+        }, no_filler, no_early);
         close(VM2{});
     });
 
@@ -374,7 +381,9 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         if (L2_ABLATE & 512) return;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            g[s] = *(const f16x8 *)(Gw + s * 1024);
+            // (the half this wave made is still in `pre`: no need to read it back)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { g[s][2 * k] = pre[4 * s + k][0]; g[s][2 * k + 1] = pre[4 * s + k][1]; }
             g[2 + s] = *(const f16x8 *)(Gp + s * 1024);
         }
     };
@@ -418,12 +427,12 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
             };
             // chunk c+1: its partial sums cross to the partner behind tile 0 (they have been final since the last barrier),
             // are taken in behind tile 1, the first GELU pairs follow
-            if constexpr (d == 0) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) send_partial(); });
+            if constexpr (d == 0) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) { if (kk == 0) send_partial(); }, no_early);
             else if constexpr (d == 1) rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, [&](int kk) __attribute__((always_inline)) {
-                if (kk == 2) absorb_load();               // (the first fragments of the tile are spent: their registers carry the sums)
-                if (kk == 3) absorb_math();
-            });
-            else rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 2>{}));
+                if (L2_ABSORB_EARLY ? kk == 1 : kk == 3) absorb_math();
+                if (!L2_ABSORB_EARLY && kk == 2) absorb_load();
+            }, [&]() __attribute__((always_inline)) { if (L2_ABSORB_EARLY) absorb_load(); });
+            else rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], pf, gelu_filler(std::integral_constant<int, d - 2>{}), no_early);
             close(VM2{});
         });
     };
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(512, 1) void layer_tail2_kernel(Tail2Args a) {
         constexpr int d = decltype(d_tag)::value, d2 = d + 2;
         rows_tile(aD, d_tag, g[0], g[1], g[2], g[3], [&](int s2) __attribute__((always_inline)) {
             if constexpr (d2 < NT) dma_down(NC - 1, d2, s2);
-        }, no_filler);
+        }, no_filler, no_early);
         if constexpr (d2 < NT) close(VM2{}); else close(VM0{});
     });
 
