@@ -689,7 +689,14 @@ def test_full_size_batch_properties(make_model, ftype, B):
     ids[B // 2] = ids[3]
     ids[B - 1] = ids[3]
     cu = (np.arange(B + 1) * 128).astype(np.int32)
+    m.profile(True)
     out = m.eval_packed(ids.reshape(-1), cu)
+    rep = m.profile_report()
+    m.profile(False)
+    # two launches per layer: the fused projection + attention kernel and the token-owning layer tail (q4 matrices are
+    # expanded to f16 at load by default, so both models take the same kernels)
+    assert set(rep) == {"embed_ln", "qkv_attention2", "layer_tail", "pool_normalize"}, sorted(rep)
+    assert rep["qkv_attention2"]["launches"] == hp.n_layer and rep["layer_tail"]["launches"] == hp.n_layer
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
