@@ -83,6 +83,11 @@ bool layer_tail2_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gem
 void launch_layer_tail2(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                         const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
                         const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
+// the same with a pair of SPECIALIST waves per token block (up-projection + GELU / down-projection), layer_tail3.hip
+bool layer_tail3_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
+void launch_layer_tail3(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
+                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
+                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);

@@ -3,7 +3,7 @@
 import json, os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, torch
-class A: steps=int(os.environ.get("STEPS","5")); warmup=2
+class A: steps=int(os.environ.get("STEPS","5")); warmup=2; repeat=int(os.environ.get("REPEAT","3")); also=False; config=1; gpus=1; inproc=False; no_cpu_baseline=True
 cfg=int(sys.argv[1]) if len(sys.argv)>1 else 1
 torch.cuda.set_device(0); dev=torch.device("cuda",0)
 with tempfile.TemporaryDirectory() as d:
