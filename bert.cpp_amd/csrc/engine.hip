@@ -217,7 +217,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_QKV2")) e->qkv2_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_GEMM256")) e->gemm256_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_TAIL")) { e->tail_ = strcmp(f, "0") != 0; e->tail2_ = strcmp(f, "2") == 0; e->tail3_ = strcmp(f, "3") == 0; }
+    if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
@@ -316,7 +316,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "qkv_att") qkv_att_ = value != "0";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
-    else if (key == "tail") { tail_ = value != "0"; tail2_ = value == "2"; tail3_ = value == "3"; }
+    else if (key == "tail") tail_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -458,22 +458,9 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         });
         }
         const bool ffn_ok = ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w);
-        if (tail_ && tail3_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail3_supported(L.o.w, L.ffi.w, L.ffo.w)) {
-            // specialist wave pairs: an up-projection + GELU wave and a down-projection wave per token block
-            timed("layer_tail3", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
-                launch_layer_tail3(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
-                                   L.ln_att_b.as<float>(), L.ffi_b.as<float>(), L.ffo_b.as<float>(),
-                                   L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
-            });
-        } else if (tail_ && tail2_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail2_supported(L.o.w, L.ffi.w, L.ffo.w)) {
-            // the same in one launch with a pair of waves per token block (two waves per SIMD)
-            timed("layer_tail2", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
-                launch_layer_tail2(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
-                                   L.ln_att_b.as<float>(), L.ffi_b.as<float>(), L.ffo_b.as<float>(),
-                                   L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
-            });
-        } else if (tail_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail_supported(L.o.w, L.ffi.w, L.ffo.w)) {
-            // token-owning waves: out-projection + LN + FFN + LN, y and the intermediate never leave the registers
+        if (tail_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail_supported(L.o.w, L.ffi.w, L.ffo.w)) {
+            // out-projection + LN + FFN + LN in one launch, a pair of specialist waves per 32 tokens: y and the intermediate
+            // never leave the chip
             timed("layer_tail", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
                 launch_layer_tail(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
                                   L.ln_att_b.as<float>(), L.ffi_b.as<float>(), L.ffo_b.as<float>(),

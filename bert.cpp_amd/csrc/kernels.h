@@ -76,18 +76,9 @@ void launch_proj_ffn_fused(const GemmWeight &Wo, const GemmWeight &W1, const Gem
                            const half_t *x, const float *bo, const float *g1, const float *beta1, half_t *ybuf,
                            const float *b1, const float *b2, const float *g2, const float *beta2, half_t *out, int M_pad,
                            hipStream_t stream);
-// Out-projection + LN + FFN + LN with token-owning waves (layer_tail.hip); f16 weights, W1 / W2 need w16p.
+// Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
+// GELU / down-projection); f16 weights, H = 256 / 384, W1 / W2 need w16p.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
-// the same with a pair of waves per token block, two waves per SIMD (layer_tail2.hip)
-bool layer_tail2_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
-void launch_layer_tail2(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
-                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
-                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
-// the same with a pair of SPECIALIST waves per token block (up-projection + GELU / down-projection), layer_tail3.hip
-bool layer_tail3_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
-void launch_layer_tail3(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
-                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
-                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);

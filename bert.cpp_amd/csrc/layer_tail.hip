@@ -1,30 +1,37 @@
-// layer_tail.hip — everything of an encoder layer after the attention, in ONE kernel in which every wave OWNS its
-// tokens (gfx950, f16 weights):
+// layer_tail.hip — everything of an encoder layer after the attention in ONE kernel, two SPECIALIST waves per SIMD
+// (gfx950, f16 weights, H = 256 / 384):
 //     y     = LayerNorm(ctx Wo^T + bo + x) * g1 + be1                     (reference bert.cpp:859-875)
 //     x_out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2       (reference bert.cpp:878-901)
 //
-// Workgroup = 128 tokens = 4 waves x 32 tokens, one wave per SIMD with the whole 512-register budget.  A wave
-// computes ALL output features of its 32 tokens, so
-//   * the MFMA B operand (tokens) never goes through LDS between the GEMMs: the LayerNorm'ed y and the GELU'ed
-//     intermediate chunk are produced in the accumulator layout (lane = token, 4-feature runs) and, converted to
-//     f16, ARE the next GEMM's B fragments — the weights are stored with the matching order inside every group
-//     of 16 k (GemmWeight::w16p), so no shuffle is needed;
-//   * both LayerNorms are wave-local (row statistics = the lane's registers + one cross-half shuffle), y is
-//     never written to HBM, and there is no barrier between a GEMM and its epilogue;
-//   * the GELU of chunk c+1 is issued as VALU filler between the MFMAs of chunk c's down-projection (one set of up-
-//     projection accumulators, two GELU'ed chunks in flight), so the matrix pipe waits for the first chunk's GELU only.
-// The intermediate dimension is processed in chunks of 64 features (up-projection tile = [64 rows x 128 k], down-
-// projection tile = [128 rows x 64 k]): 32 up-projection accumulator registers next to the 192 output accumulators fit
-// the 256 AccVGPRs, and the tile loop runs without a single spill — a scratch reload inside the loop would queue behind
-// the weight tiles in flight (vmcnt is in-order) and serialise the whole pipeline.
-// Only the weight tiles (16 KiB) are shared: they stream through a 3-slot LDS ring by LDS-DMA,
-// two tiles ahead, one barrier per tile.  Each wave hides its own LDS latency (tile_stream.h, hand-issued reads):
-// the fragments of a tile are read in two halves, and the second half's MFMAs run after the next barrier, under
-// the reads of the next tile.
+// History: the round-1/2 form of this kernel gave ONE wave per SIMD 32 tokens x all features; its steady state carried 5.7
+// non-MFMA instructions per MFMA (tools/isa_gaps.py: 1.9 VALU + 0.7 transcendental + 0.7 accvgpr moves + 1.4 LDS + 0.25 DMA +
+// 0.5 SALU) against the <= 5 a lone wave can hide per v_mfma_f32_32x32x16 gap, and the wave issued all of it in order: 75
+// cycles per MFMA instead of 32.  A round-2 experiment put two SYMMETRIC waves on a SIMD (both up-project, split by K, both
+// down-project): per chunk a 32 x 32 f32 partial block and half a GELU'ed chunk crossed LDS in both directions with two
+// dependent hand-overs, a quarter of its time, and it ended level.  Both are gone; this is the only form.
 //
-// LDS: 4 x 24 KiB wave-private staging (x rows -> y fragments -> output rows), 48 KiB ring, biases / LayerNorm
-// parameters.  Registers (H = 384): 192 output accumulators + 32 up-projection accumulators + 2 x 16 (GELU'ed
-// chunks) + 64 weight fragments + 32 y fragments.
+// Here a token block of 32 belongs to a pair of waves with DIFFERENT jobs (workgroup = 128 tokens = 4 pairs, 512 threads):
+//   * wave U (up):   holds the LayerNorm'ed y of its 32 tokens as 8 NT B fragments in REGISTERS for the whole feed-forward
+//                    (no y staging in LDS, no y re-reads), multiplies the up-projection tiles ([64 rows x 128 k], 16 MFMAs per
+//                    tile into one of TWO sets of 32 accumulators), and runs the GELU of the previous chunk as VALU filler
+//                    between those MFMAs, in packed f16, straight into the accumulator layout that IS the down-projection's
+//                    B fragment (GemmWeight::w16p);
+//   * wave D (down): holds ALL 4 NT output accumulator blocks of the same 32 tokens (192 registers at H = 384, initial value
+//                    y + b2: the residual), multiplies the down-projection tiles ([128 rows x 64 k], 16 MFMAs per tile) with
+//                    the GELU'ed chunk U published — four ds_write_b128 by U, four ds_read_b128 by D per chunk of 64
+//                    intermediate features, ONE direction, riding on the tile barriers (no extra synchronisation);
+//                    it issues no VALU work at all in the loop, so its stream is MFMAs + fragment reads + its share of the DMA.
+// The two streams are decoupled by two chunks (U: UP(c) + gelu(c-1), D: DOWN(c-2)); one tile interval = one UP tile for U
+// and one DOWN tile for D = 32 MFMAs per SIMD between two workgroup barriers (layer_tail: 16), and what one wave issues
+// beside its MFMAs (fragment reads, GELU, DMA requests, waits) sits under the other's MFMAs.
+// Out-projection: both waves, split by output features (2 NT blocks each, x + bo as the initial value), two tiles per
+// interval; LayerNorm 1: row sums cross LDS (one float pair per token), then each wave's half of y crosses once (4 NT
+// fragments each way) — U needs all of y as B fragments, D all of y as its accumulators' initial value.
+// LayerNorm 2 is local to D (it owns whole rows); both waves store the rows.
+//
+// LDS: two rings of 3 x 16 KiB (UP tiles / DOWN tiles; the out-projection uses both), 4 x 2 x 4 KiB GELU'ed chunks,
+// parameters.  Registers (H = 384): U 96 (y) + 64 (two sets of up-projection accumulators) + 48 (fragments) + 16 (chunk
+// being GELU'ed); D 192 + 32 (fragments) + 16 (chunk).
 #include "tile_stream.h"
 
 namespace bert_hip {
@@ -32,30 +39,45 @@ namespace bert_hip {
 namespace {
 
 constexpr int LT_TILE = 16384;
-
-// LT_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no GELU arithmetic, bit 2 no tile barrier,
-// bit 3 no fragment reads, bit 4 no MFMAs, bit 5 no GELU filler in the last interval of a chunk, bit 6 no GELU filler at all, bit 7 no LDS-read waits — what a component costs is the time its removal saves (tools/variant.sh)
+// LT_ABLATE (tuning builds only, results are wrong): bit 0 no weight DMA, bit 1 no GELU arithmetic, bit 2 no fragment reads,
+// bit 3 no MFMAs, bit 4 no chunk publish / fetch, bit 5 LayerNorm 1 without statistics and parameter reads, bit 6 no out-projection
+// fragment reads / MFMAs, bit 7 LayerNorm 2 without parameter reads
 #ifndef LT_ABLATE
 #define LT_ABLATE 0
 #endif
-// LT_GROLE: -1 = the two GELU'ed-chunk buffers alternate roles with the chunk parity; 0 / 1 = the down-projection always
-// reads g[LT_GROLE], the filler always writes the other one, which is copied over once per chunk
-#ifndef LT_GROLE
-#define LT_GROLE 1
+// priority of the U waves in the feed-forward loop (D stays at 0)
+#ifndef LT_UPRIO
+#define LT_UPRIO 1
 #endif
-// LT_GELU16: the GELU of the intermediate is evaluated in packed f16 (two elements per instruction where the ISA has a
-// packed form; the reference reads it from an f16 table, ggml_gelu_f16), 0 = f32 arithmetic per element
-#ifndef LT_GELU16
-#define LT_GELU16 1
+#ifndef LT_GELU_BATCH
+#define LT_GELU_BATCH 0
 #endif
-// LT_BIASINIT: the up-projection accumulators start from the bias of their chunk (written where they used to be
-// zeroed) instead of the bias being added in front of the GELU
-#ifndef LT_DMA_SPREAD
-#define LT_DMA_SPREAD 1
+// D's requests of an interval: 0 = all eight pieces behind its first MFMA group, 1 = the up-projection tile's behind the first,
+// the down-projection tile's behind the second
+#ifndef LT_DMA_SPLIT
+#define LT_DMA_SPLIT 1
 #endif
-#ifndef LT_BIASINIT
-#define LT_BIASINIT 1
+#ifndef LT_DPRIO
+#define LT_DPRIO 0
 #endif
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Tuning aid (-DBERT_HIP_TIMELINE, `make timeline`): shader-clock stamps of pair 0 of every workgroup: [0, 128) U behind
+// the barrier of interval i, [128, 256) U in front of it, [256, 384) D in front of it, [384, 512) phases outside the loops
+#ifdef BERT_HIP_TIMELINE
+static __device__ unsigned long long g_tl_tail[256 * 512];
+#define LT_STAMP(sel, i) do { const int tl_i = (i); if ((sel) && tl_i < 512) g_tl_tail[(blockIdx.x & 255) * 512 + tl_i] = __builtin_readcyclecounter(); } while (0)
+#ifdef LT_FINE
+#define LT_STAMP_FINE(sel, i) LT_STAMP(sel, i)
+#else
+#define LT_STAMP_FINE(sel, i) do { } while (0)
+#endif
+#else
+#define LT_STAMP_FINE(sel, i) do { } while (0)
+#define LT_STAMP(sel, i) do { } while (0)
+#endif
+
 struct TailArgs {
     const half_t *ctx, *x;            // [T_pad][H]
     const half_t *wo;                 // [H_pad][H] f16
@@ -66,125 +88,123 @@ struct TailArgs {
     int I;
 };
 
-// tile kinds of the stream
-constexpr int K_NONE = 0, K_PROJ = 1, K_UP = 2, K_DOWN = 3;
-template <int KIND, int I0, int I1>
-struct TileDesc {
-    static constexpr int kind = KIND, i0 = I0, i1 = I1;
-};
-using NoTile = TileDesc<K_NONE, 0, 0>;
-
-// (LT_ABLATE bit 7: no wait for LDS reads anywhere — what their exposed latency costs: 1 %)
-#if LT_ABLATE & 128
-#define LT_LGKM(n) "15"
-#else
-#define LT_LGKM(n) #n
-#endif
-__device__ __forceinline__ void wait_lgkm8(f16x8 (&f)[8]) {
-    asm volatile("s_waitcnt lgkmcnt(" LT_LGKM(8) ")"
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]) : : "memory");
+// retire all but the newest N hand-issued LDS reads; the four fragments named are the ones whose MFMAs follow
+template <int N>
+__device__ __forceinline__ void wait_frags(f16x8 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N) : "memory");
 }
-__device__ __forceinline__ void wait_lgkm12(f16x8 (&f)[8], f16x8 (&y)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(" LT_LGKM(12) ")"
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
-                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : : "memory");
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" : : "n"(N) : "memory");
 }
-// GELU filler placement: the 16 element pairs of gelu(c+1) sit behind the MFMAs of the NT intervals of DOWN(c); the
-// first 8 MFMAs of interval 0 still finish UP(c+1), which leaves 8 + (NT-1)*16 usable slots.  Pair q sits at usable
-// slot floor(q * total / 16).  lt_pair_of: the pair at MFMA slot `slot16` (0..15) of interval d, or -1;
-// lt_pair_rank: how many pairs sit in slots grp*8 .. grp*8+k-1 of that interval.
-template <int NT>
-constexpr int lt_pair_of(int d, int slot16) {
-    static_assert(NT >= 2, "16 pairs need at least 16 usable slots");
-    const int first = d == 0 ? 8 : 0, before = d == 0 ? 0 : 8 + (d - 1) * 16, total = 8 + (NT - 1) * 16;
-    if (slot16 < first) return -1;
-    const int u = before + slot16 - first;
-    const int q = (u * 16 + total - 1) / total;               // smallest q with q * total / 16 >= u
-    return (q < 16 && (q * total) / 16 == u) ? q : -1;
+// a hand-read register handed to its users (behind the wait that retired the read)
+template <class V>
+__device__ __forceinline__ void landed(V &v) { asm volatile("" : "+v"(v)); }
+// closing barrier of a tile interval: this wave's DMA pieces of the NEXT tile have landed (all but the newest VM), its LDS
+// reads and writes are complete
+template <int VM>
+__device__ __forceinline__ void close_interval() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(VM) : "memory");
 }
-template <int NT>
-constexpr int lt_pair_rank(int d, int grp, int k) {
-    int n = 0;
-    for (int kk = 0; kk < k; ++kk) n += lt_pair_of<NT>(d, grp * 8 + kk) >= 0;
-    return n;
+template <int VM>
+__device__ __forceinline__ void close_interval(f16x8 (&f)[4]) {
+    asm volatile("s_waitcnt vmcnt(%4) lgkmcnt(0)\n\ts_barrier" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(VM) : "memory");
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
-__device__ __forceinline__ f32x2 lds_read_b64_u(unsigned addr) {
+__device__ __forceinline__ f32x2 lds_read_b64_h(unsigned addr) {
     f32x2 v;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
-// hands N hand-read bias pairs to their users; WAIT: after retiring everything but the newest 8 LDS reads
-// (every operand names a different register pair: a repeated operand would be COPIED before the asm, i.e. before its
-// read has landed)
-#define LT_FENCE(TEXT, ...) asm volatile(TEXT : __VA_ARGS__ : : "memory")
-template <int N, bool WAIT>
-__device__ __forceinline__ void bias_fence_n(f32x2 (&b)[6]) {
-    static_assert(N >= 0 && N <= 6, "");
-    if constexpr (WAIT) {
-        if constexpr (N == 1) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]));
-        if constexpr (N == 2) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]));
-        if constexpr (N == 3) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
-        if constexpr (N == 4) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-        if constexpr (N == 5) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
-        if constexpr (N == 6) LT_FENCE("s_waitcnt lgkmcnt(8)", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
-    } else {
-        if constexpr (N == 1) LT_FENCE("", "+v"(b[0]));
-        if constexpr (N == 2) LT_FENCE("", "+v"(b[0]), "+v"(b[1]));
-        if constexpr (N == 3) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]));
-        if constexpr (N == 4) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
-        if constexpr (N == 5) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]));
-        if constexpr (N == 6) LT_FENCE("", "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
-    }
+template <int OFF>
+__device__ __forceinline__ f32x4 lds_read_f32x4_h(unsigned addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
 }
-// tile barrier: this wave's share of the next tile has landed (all but the newest VM pieces), every hand-issued
-// read has returned (the second-half fragments are named: their MFMAs run after the barrier)
-template <int VM>
-__device__ __forceinline__ void tile_barrier(f16x8 (&f)[8], f16x8 (&y)[4]) {
-#if LT_ABLATE & 4
-#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(" LT_LGKM(0) ")"
-#else
-#define LT_BARRIER_TEXT "s_waitcnt vmcnt(%12) lgkmcnt(" LT_LGKM(0) ")\n\ts_barrier"
-#endif
-    asm volatile(LT_BARRIER_TEXT
-                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]),
-                   "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]) : "n"(VM) : "memory");
+template <int OFF>
+__device__ __forceinline__ f16x8 frag_read(unsigned addr) {
+    if (LT_ABLATE & 4) { f16x8 z = (f16x8)(_Float16)0.f; asm volatile("" : "+v"(z) : "v"(addr)); return z; }
+    return lds_read_b128_u<OFF>(addr);
+}
+
+// LDS-DMA by hand (global_load_lds_dwordx4, 1 KiB per wave-instruction): scalar base + 32-bit lane offset, so no 64-bit
+// address arithmetic on the vector unit and one VGPR per distinct lane pattern.  M0 = LDS address of the wave's first piece,
+// set once per tile; the instruction offset (which moves BOTH the global and the LDS address) selects the piece, the
+// scalar base compensates.  The compiler never touches M0 in this kernel (no LDS-DMA builtin, no indirect indexing).
+__device__ __forceinline__ void dma_m0(unsigned lds) {
+    if (LT_ABLATE & 1) return;
+    asm volatile("s_mov_b32 m0, %0" : : "s"(lds) : "memory");
+}
+template <int PIECE>
+__device__ __forceinline__ void dma_piece(const char *gbase, unsigned voff) {
+    if (LT_ABLATE & 1) return;
+    asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" : : "v"(voff), "s"(gbase - PIECE * 1024), "n"(PIECE * 1024) : "memory");
+}
+
+__device__ __forceinline__ f32x16 mfma16(const f16x8 &a, const f16x8 &b, const f32x16 &c) {
+    if (LT_ABLATE & 8) { f32x16 r = c; asm volatile("" : "+v"(r[0]) : "v"(a), "v"(b)); return r; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 }  // namespace
 
 template <int NT>
-__global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int H = 128 * NT, KU = 2 * NT, NB = 4 * NT, NQ = 8 * NT;
-    constexpr int S_BYTES = 64 * H;                           // 32 tokens x H halfs per wave
-    const int I = a.I, NC = I / 64;                           // chunks of 64 intermediate features
+    constexpr int H = 128 * NT, NBH = 2 * NT, NB = 4 * NT, NQ = 8 * NT, NYH = 4 * NT;
+    constexpr int P = NT * NT;                                // out-projection intervals (two [128 x 64] tiles each)
+    constexpr int NG = NT;                                    // intervals over which the GELU of a chunk is spread
+    constexpr int LAGT = NT + NG;                             // D runs this many intervals behind U
+    const int I = a.I, NC = I / 64;                           // chunks of 64 intermediate features (even, >= 2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = wave & 3, role = wave >> 2;                 // token block; 0 = U (up-projection + GELU), 1 = D (down-projection)
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tok_w = blockIdx.x * 128 + wave * 32;           // first token of this wave
+    const int tok_w = blockIdx.x * 128 + t * 32;              // first token of this pair
 
-    char *S = smem + wave * S_BYTES;
-    char *ring = smem + 4 * S_BYTES;
-    float *cbo = (float *)(ring + 3 * LT_TILE);
-    float *cg1 = cbo + H, *cbe1 = cg1 + H, *cb2 = cbe1 + H, *cg2 = cb2 + H, *cbe2 = cg2 + H, *cb1 = cbe2 + H;
+    char *ringU = smem;                                       // 3 x 16 KiB
+    char *ringD = smem + 3 * LT_TILE;                         // 3 x 16 KiB
+    char *G = smem + 6 * LT_TILE;                             // [4 pairs][2][4 KiB] GELU'ed chunks
+    float *ST = (float *)(G + 32768);                         // 8 x 32 x {sum, sum of squares}
+    float *cbo = ST + 8 * 64;
+    float *cg1 = cbo + H, *cbe1 = cg1 + H, *cb2 = cbe1 + H, *cg2 = cb2 + H, *cbe2 = cg2 + H, *cb1 = cbe2 + H;   // cb1: I + 128 floats
 
-    // ---- prologue: parameters -> LDS; this wave's x rows -> S (16-byte unit of (token, 8-feature chunk c) at
-    // position c*32 + ((token + c) & 31): conflict-free 8-byte reads in the accumulator layout)
-    for (int i = tid; i < H; i += 256) {
-        cbo[i] = a.bo[i]; cg1[i] = a.g1[i]; cbe1[i] = a.be1[i]; cb2[i] = a.b2[i]; cg2[i] = a.g2[i]; cbe2[i] = a.be2[i];
-    }
-    for (int i = tid; i < I; i += 256) cb1[i] = a.b1[i];
-    {
-        const half_t *xw = a.x + (size_t)tok_w * H;
+    {   // parameters -> LDS: every load of a thread in flight together (one round trip, not one per loop iteration)
+        constexpr int NPB = 4;                                // b1: up to 512 * 4 * NPB floats
+        const float *const src[6] = {a.bo, a.g1, a.be1, a.b2, a.g2, a.be2};
+        float pv[6];
+        f32x4 bq[NPB];
 #pragma unroll
-        for (int p = 0; p < H / 16; ++p) {
-            const int u = p * 64 + lane, c = u >> 5, tok = ((u & 31) - c) & 31;
-            __builtin_amdgcn_global_load_lds(AS_GLOBAL(xw + (size_t)tok * H + c * 8), AS_LDS(S + p * 1024), 16, 0, 0);
+        for (int k = 0; k < 6; ++k) pv[k] = tid < H ? src[k][tid] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int i4 = (k * 512 + tid) * 4;
+            bq[k] = i4 < I ? *(const f32x4 *)(a.b1 + i4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < H) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) cbo[k * H + tid] = pv[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int i4 = (k * 512 + tid) * 4;
+            if (i4 < I + 128) *(f32x4 *)(cb1 + i4) = bq[k];
         }
     }
-    // attention context of this wave's tokens as B fragments, straight into registers (k order as stored)
+    // ---- out-projection accumulators start from x + bo: own block b = n3 * 2 + obp holds features
+    // n3*128 + role*64 + obp*32 + 8 (r >> 2) + 4 hi + (r & 3) of token l31 in register r.  x now (one round trip), the bias
+    // from LDS behind the first barrier: requesting both from HBM at once needs 144 registers next to the 96 of the context.
+    f32x16 accp[NBH];
+    f16x4 xv[NBH][4];
+    {
+        const half_t *xr = a.x + (size_t)(tok_w + l31) * H + role * 64 + 4 * hi;
+#pragma unroll
+        for (int b = 0; b < NBH; ++b)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) xv[b][gq] = *(const f16x4 *)(xr + (b >> 1) * 128 + (b & 1) * 32 + 8 * gq);
+    }
+    // attention context of the pair's tokens as B fragments, straight into registers (k order as stored)
     f16x8 bf[NQ];
     {
         const half_t *cw = a.ctx + (size_t)(tok_w + l31) * H + 8 * hi;
@@ -192,482 +212,201 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
         for (int q = 0; q < NQ; ++q) bf[q] = *(const f16x8 *)(cw + 16 * q);
     }
 
-    // ---- weight-tile stream: [128 rows x 64 k] tiles, 16 pieces of 1 KiB, 4 per wave
-    // ([64 rows x 128 k] for the up-projection: 256-byte rows, 16-byte chunk ^ (row & 15), 4 rows per piece).
-    // The feed-forward's lane offsets and addresses are (re)computed after the out-projection from an opaque copy of
-    // the lane id: values that live across the out-projection (where the 96 context registers are alive) get
-    // spilled for their whole life, and a reload inside the tile loop queues behind the DMA in flight.
-    // Lane offsets of the DMA pieces, kept in few registers: piece i of this wave covers rows (wave*4+i)*8.. of a
-    // [128 x 64] tile; the row part of i goes into the scalar base, the swizzle alternates between two values
-    // (even / odd i).  For the [64 x 128] up-projection tile (rows (wave*4+i)*4..) the swizzle of piece i is the one
-    // of piece 0 with i XORed into bits 6..7.
-    unsigned offHe, offHo, offIe, offIo, offUb, offUx;
-    auto lane_offsets = [&](int ln) __attribute__((always_inline)) {
-        const int ch0 = (ln & 7) ^ (ln >> 4), row = wave * 32 + (ln >> 3);
-        offHe = (unsigned)(row * H * 2 + ch0 * 16);
-        offHo = (unsigned)(row * H * 2 + (ch0 ^ 4) * 16);
-        offIe = (unsigned)(row * I * 2 + ch0 * 16);
-        offIo = (unsigned)(row * I * 2 + (ch0 ^ 4) * 16);
-        offUb = (unsigned)((wave * 16 + (ln >> 4)) * H * 2);
-        offUx = (unsigned)(((ln & 15) ^ (ln >> 4)) * 16);
+    // ---- weight-tile stream.  A tile is 16 pieces of 1 KiB; the four waves of a role move the tiles of "their" ring, four
+    // pieces each: [128 rows x 64 k] tiles (128-byte rows): piece i of wave t covers rows (t*4+i)*8 .. +8, 16-byte chunk c of a
+    // row at chunk c ^ ((row >> 1) & 7); [64 rows x 128 k] tiles (256-byte rows): rows (t*4+i)*4 .. +4, chunk c at c ^ (row & 15).
+    // Lane offsets in few registers: the row part of i goes into the scalar base, the swizzle alternates between two values
+    // (even / odd i) resp. is the one of piece 0 with i XORed into bits 6..7.
+    // offR[0/1]: even / odd pieces of a [128 x 64] tile with row pitch `pitch` halfs; offU: piece 0 of a [64 x 128] tile
+    // (piece i: ^ (i << 6); the row part is a multiple of 256 bytes).  Computed per phase from an opaque copy of the lane id:
+    // values that live across phases get spilled for their whole life.
+    auto rows_offset = [&](int pitch) __attribute__((always_inline)) {        // even pieces; odd pieces: ^ 64 (the row part is a multiple of 128)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int ch0 = (ln & 7) ^ (ln >> 4), row = t * 32 + (ln >> 3);
+        return (unsigned)(row * pitch * 2 + ch0 * 16);
     };
-    lane_offsets(lane);
-    const half_t *const wo = a.wo, *const w1p = a.w1p, *const w2p = a.w2p;     // (locals: keeps the argument struct out of scratch)
-    // PC = piece of this wave to request (0..3), or -1 for all four
-    using ALLP = std::integral_constant<int, -1>;
-    auto dma128 = [&](const half_t *base, unsigned oe, unsigned oo, int row_bytes, int slot, auto pc_tag) __attribute__((always_inline)) {
-        constexpr int PC = decltype(pc_tag)::value;
-        char *dst = ring + slot * LT_TILE + wave * 4096;
-        static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_tag)::value;
-            if constexpr ((PC < 0 || PC == i) && !(LT_ABLATE & 1))
-                __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 8 * row_bytes + ((i & 1) ? oo : oe)),
-                                                 AS_LDS(dst + i * 1024), 16, 0, 0);
-        });
+    const half_t *const wo = a.wo, *const w1p = a.w1p, *const w2p = a.w2p;
+    auto dma128 = [&](const half_t *base, unsigned oe, int row_bytes, unsigned tile) __attribute__((always_inline)) {
+        const char *b = (const char *)base;
+        dma_m0(tile + (unsigned)(t * 4096));
+        dma_piece<0>(b, oe);
+        dma_piece<1>(b + (size_t)8 * row_bytes, oe ^ 64u);
+        dma_piece<2>(b + (size_t)16 * row_bytes, oe);
+        dma_piece<3>(b + (size_t)24 * row_bytes, oe ^ 64u);
     };
-    auto dma_proj = [&](int n3, int kt, int slot, auto pc) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offHe, offHo, H * 2, slot, pc); };
-    auto dma_down = [&](int c, int n3, int slot, auto pc) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offIe, offIo, I * 2, slot, pc); };
-    auto dma_up = [&](int c, int j, int slot, auto pc_tag) __attribute__((always_inline)) {
-        constexpr int PC = decltype(pc_tag)::value;
-        const half_t *base = w1p + (size_t)c * 64 * H + j * 128;
-        char *dst = ring + slot * LT_TILE + wave * 4096;
-        static_for<4>([&](auto i_tag) __attribute__((always_inline)) {
-            constexpr int i = decltype(i_tag)::value;
-            if constexpr ((PC < 0 || PC == i) && !(LT_ABLATE & 1))
-                __builtin_amdgcn_global_load_lds(AS_GLOBAL((const char *)base + (size_t)i * 4 * H * 2 + (offUb + (offUx ^ (unsigned)(i << 6)))),
-                                                 AS_LDS(dst + i * 1024), 16, 0, 0);
-        });
+    const unsigned ldsU = lds_addr(ringU), ldsD = lds_addr(ringD);
+    const unsigned offH = rows_offset(H);
+    auto dma_proj = [&](int n3, int kt, unsigned tile) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offH, H * 2, tile); };
+    auto up_offset = [&]() __attribute__((always_inline)) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return (unsigned)((t * 16 + (ln >> 4)) * H * 2 + (((ln & 15) ^ (ln >> 4)) * 16));
+    };
+    auto dma_up = [&](int c, int j, unsigned offU, unsigned tile) __attribute__((always_inline)) {
+        const char *b = (const char *)(w1p + (size_t)c * 64 * H + j * 128);
+        dma_m0(tile + (unsigned)(t * 4096));
+        dma_piece<0>(b, offU);
+        dma_piece<1>(b + (size_t)4 * H * 2, offU ^ 64u);
+        dma_piece<2>(b + (size_t)8 * H * 2, offU ^ 128u);
+        dma_piece<3>(b + (size_t)12 * H * 2, offU ^ 192u);
     };
 
-    // ---- per-lane LDS addresses
-    // weight fragment of k-step kk: the swizzles are XORs of the 16-byte chunk index 2*kk + hi, so the address of
-    // k-step kk is the address of k-step 0 with kk XORed into bits 5.. (one register per tile shape instead of 4 / 8)
-    unsigned aA0 = lds_addr(ring) + off64(l31, hi);                                   // [128 x 64]: + ob * 4 KiB + slot * 16 KiB
-    unsigned aU0 = lds_addr(ring) + l31 * 256 + ((hi ^ (l31 & 15)) << 4);            // [64 x 128]: + fb * 8 KiB + slot * 16 KiB
-    unsigned aY = lds_addr(S) + lane * 16;                    // y fragment q at + q * 1 KiB
-    unsigned aB = lds_addr(cb1) + hi * 16;                    // up-projection biases of a lane's features: + chunk * 256 B
+    // ---- fragment addresses: k-step kk of a tile = the address of k-step 0 with kk XORed into bits 5.. (the slot offsets are
+    // multiples of 8 KiB, so the XOR commutes with adding them)
+    const unsigned aR = lds_addr(ringU) + (unsigned)off64(l31, hi);                      // [128 x 64]: + ob * 4096
+    const unsigned aUp = lds_addr(ringU) + (unsigned)(l31 * 256 + ((hi ^ (l31 & 15)) << 4));   // [64 x 128]: + fb * 8192
 
-    f32x16 acc2[NB], accU[2];
-    f16x8 g[2][4];                                            // GELU'ed chunks (two in flight) as B fragments
-    f16x8 F[2][8], Y[2][4];                                   // weight fragments [half][...], y fragments [half][i]
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[n][r] = 0.f;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) F[hh][j] = (f16x8)(_Float16)0;
-        Y[hh][0] = Y[hh][1] = Y[hh][2] = Y[hh][3] = (f16x8)(_Float16)0;
-    }
-
-    // fragment reads of one half of the tile in ring slot `slot_off`.  [128 x 64] tiles: k-steps 2*half + i, 4 row
-    // blocks, F[half][ob*2 + i].  Up-projection [64 x 128] tiles: k-steps 4*half + i, 2 row blocks, F[half][fb*4 + i],
-    // plus the 4 y fragments of those k-steps.
-    auto read_half = [&](auto desc, auto half_tag, unsigned slot_off) __attribute__((always_inline)) {
-        using D = decltype(desc);
-        constexpr int half = decltype(half_tag)::value;
-        if constexpr (LT_ABLATE & 8) {
-        } else if constexpr (D::kind == K_UP) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned ad = (aU0 ^ (unsigned)((half * 4 + i) << 5)) + slot_off;
-                F[half][0 + i] = lds_read_b128_u<0>(ad);
-                F[half][4 + i] = lds_read_b128_u<8192>(ad);
-            }
-            Y[half][0] = lds_read_b128_u<(8 * D::i1 + 4 * half + 0) * 1024>(aY);
-            Y[half][1] = lds_read_b128_u<(8 * D::i1 + 4 * half + 1) * 1024>(aY);
-            Y[half][2] = lds_read_b128_u<(8 * D::i1 + 4 * half + 2) * 1024>(aY);
-            Y[half][3] = lds_read_b128_u<(8 * D::i1 + 4 * half + 3) * 1024>(aY);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned ad = (aA0 ^ (unsigned)((half * 2 + i) << 5)) + slot_off;
-                F[half][0 + i] = lds_read_b128_u<0>(ad);
-                F[half][2 + i] = lds_read_b128_u<4096>(ad);
-                F[half][4 + i] = lds_read_b128_u<8192>(ad);
-                F[half][6 + i] = lds_read_b128_u<12288>(ad);
-            }
-        }
-    };
-    // the 8 MFMAs of one half of a tile.  PROJ <n3, kt>: acc2[n3*4+ob] += Wo x ctx;  UP <0, j>: accU += W1 x y;
-    // DOWN <gpar, n3>: acc2[n3*4+ob] += W2 x gelu chunk in g[gpar]
-    auto mma_half = [&](auto desc, auto half_tag, auto &&fill) __attribute__((always_inline)) {
-        using D = decltype(desc);
-        constexpr int half = decltype(half_tag)::value;
-        // fill(k): VALU filler issued behind the k-th MFMA of the half (k = 0..7), in program order
-        if constexpr (LT_ABLATE & 16) {
-            static_for<8>([&](auto k_tag) __attribute__((always_inline)) { fill(k_tag); });
-        } else if constexpr (D::kind == K_UP) {
-            static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
-                constexpr int k = decltype(k_tag)::value, i = k >> 1, fb = k & 1;
-                accU[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][fb * 4 + i], Y[half][i], accU[fb], 0, 0, 0);
-                fill(k_tag);
-            });
-        } else {
-            static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
-                constexpr int k = decltype(k_tag)::value, i = k >> 2, ob = k & 3;
-                if constexpr (D::kind == K_PROJ)
-                    acc2[D::i0 * 4 + ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][ob * 2 + i], bf[4 * D::i1 + 2 * half + i], acc2[D::i0 * 4 + ob], 0, 0, 0);
-                else
-                    acc2[D::i1 * 4 + ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F[half][ob * 2 + i], g[D::i0][2 * half + i], acc2[D::i1 * 4 + ob], 0, 0, 0);
-                fill(k_tag);
-            });
-        }
-    };
-
-    int slot = 0;                                             // ring slot of the current tile
+    int slot = 0;                                             // ring slot of the current interval (both rings)
     [[maybe_unused]] int tl = 1;
-    TL_STAMP(0);
-    using H0 = std::integral_constant<int, 0>;
-    using H1 = std::integral_constant<int, 1>;
-    // One interval = one tile.  On entry the tile is complete in LDS for every wave.  `prev` = the tile whose second
-    // half is still owed (NoTile after a drain), `prefetch(slot)` requests tile +2, `filler(group, k)` is VALU work
-    // issued behind the k-th MFMA of the owed half (group 0) / of this tile's first half (group 1), VM = DMA pieces of this wave that may stay in flight at the closing barrier.
-    auto interval = [&](auto cur, auto prev, auto vm_tag, auto &&prefetch, auto &&filler, auto &&pre, auto &&fence) __attribute__((always_inline)) {
-        using C = decltype(cur);
-        using P = decltype(prev);
-        constexpr int VM = decltype(vm_tag)::value;
-        const unsigned so = (unsigned)slot * LT_TILE;
-        TL_STAMP(tl++);
-        const int pslot = slot == 0 ? 2 : slot - 1;           // slot + 2 (mod 3): read one tile ago, free since the barrier
-        // pre(group) issues the LDS reads the fillers of that group need (by hand, like the fragments: a compiler-issued
-        // read is retired with lgkmcnt(0), which would wait for every fragment read in flight); fence(group) hands them over
-        pre(H0{});
-        read_half(cur, H0{}, so);
-        fence(H0{});
-        // the 4 DMA pieces go behind MFMAs 1, 3, 5, 7 of the owed half (a piece costs >= 60 issue cycles, an MFMA covers 32)
-        // LT_DMA_SPREAD: behind MFMAs 1 and 5 of the owed half and of this tile's first half instead
-        if constexpr (P::kind != K_NONE)
-            mma_half(prev, H1{}, [&](auto k) __attribute__((always_inline)) {
-                constexpr int kk = decltype(k)::value;
-                if constexpr (LT_DMA_SPREAD) {
-                    if constexpr (kk == 1 || kk == 5) prefetch(pslot, std::integral_constant<int, (kk >> 2)>{});
-                } else {
-                    if constexpr (kk & 1) prefetch(pslot, std::integral_constant<int, (kk >> 1)>{});
-                }
-                filler(H0{}, k);
-            });
-        else prefetch(pslot, ALLP{});
-        pre(H1{});
-        read_half(cur, H1{}, so);
-        if constexpr (C::kind == K_UP) wait_lgkm12(F[0], Y[0]); else wait_lgkm8(F[0]);
-        fence(H1{});
-        mma_half(cur, H0{}, [&](auto k) __attribute__((always_inline)) {
-            constexpr int kk = decltype(k)::value;
-            if constexpr (LT_DMA_SPREAD && P::kind != K_NONE && (kk == 1 || kk == 5)) prefetch(pslot, std::integral_constant<int, 2 + (kk >> 2)>{});
-            filler(H1{}, k);
-        });
-        // the first-half MFMAs cover the second-half reads; left alone the scheduler sinks them below the barrier, whose
-        // lgkmcnt(0) then waits for those reads with an empty matrix pipe
-        __builtin_amdgcn_sched_barrier(0);
-        tile_barrier<VM>(F[1], Y[1]);
-        slot = slot == 2 ? 0 : slot + 1;
-    };
-    auto nothing = [](auto, auto) __attribute__((always_inline)) {};
-    auto nothing1 = [](auto) __attribute__((always_inline)) {};
-    auto drain = [&](auto prev) __attribute__((always_inline)) { mma_half(prev, H1{}, [](auto) __attribute__((always_inline)) {}); };
-    using VM4 = std::integral_constant<int, 4>;
-    using VM0 [[maybe_unused]] = std::integral_constant<int, 0>;
-
-    // GELU of fragment j (features 32*(j>>1) + 16*(j&1) .. +16 of chunk c) of the up-projection accumulators into
-    // g[par], in four steps of two elements so that it can be spread behind the MFMAs of an interval (a wave's VALU work
-    // only overlaps its own MFMAs if it is issued between them)
-    auto gelu_pair = [&](auto par_tag, auto j_tag, auto p_tag, f32x2 b) __attribute__((always_inline)) {
-        constexpr int par = decltype(par_tag)::value, j = decltype(j_tag)::value, fb = j >> 1, s = j & 1;
-        constexpr int p = decltype(p_tag)::value;             // elements 2p, 2p+1 of the fragment = registers 8s + 2p, +1
-        constexpr int e0 = 2 * p;
-        // b = the biases of THIS chunk (added here) or, with LT_BIASINIT, of the chunk the accumulators serve next
-        const float x0 = LT_BIASINIT ? accU[fb][8 * s + e0] : accU[fb][8 * s + e0] + b[0];
-        const float x1 = LT_BIASINIT ? accU[fb][8 * s + e0 + 1] : accU[fb][8 * s + e0 + 1] + b[1];
-        if constexpr (LT_ABLATE & 2) {
-            g[par][j][e0] = (_Float16)x0; g[par][j][e0 + 1] = (_Float16)x1;
-        } else if constexpr (LT_GELU16) {
-            const f16x2_t gv = gelu_pk16(x0, x1);
-            g[par][j][e0] = gv[0]; g[par][j][e0 + 1] = gv[1];
-        } else {
-            g[par][j][e0] = (_Float16)gelu_fast(x0); g[par][j][e0 + 1] = (_Float16)gelu_fast(x1);
-        }
-        accU[fb][8 * s + e0] = LT_BIASINIT ? b[0] : 0.f;
-        accU[fb][8 * s + e0 + 1] = LT_BIASINIT ? b[1] : 0.f;
-    };
-    // bias of pair (j, p) of a chunk: features 32fb + 16s + 4hi + {2p, 2p+1} (p < 2) or + 8 + {2p-4, 2p-3}, as a float offset
-    // into the chunk's 64 biases without the 4hi part
-    auto bias_off = [](int j, int p) constexpr { return 32 * (j >> 1) + 16 * (j & 1) + (p < 2 ? 2 * p : 4 + 2 * p); };
+    [[maybe_unused]] const bool tlU = tid == 0, tlD = tid == 256;
+    LT_STAMP(tlU, 0);
+    // (stamps: in front of the closing barrier per role, behind it for U)
+    auto pre_close = [&]() __attribute__((always_inline)) { LT_STAMP_FINE(tlU, 128 + tl); LT_STAMP_FINE(tlD, 256 + tl); };
+    auto next_slot = [&]() __attribute__((always_inline)) { slot = slot == 2 ? 0 : slot + 1; LT_STAMP(tlU, tl); ++tl; };
+    auto slot_plus2 = [&]() __attribute__((always_inline)) { return slot == 0 ? 2 : slot - 1; };
 
     // ================================ out-projection ================================
-    dma_proj(0, 0, 0, ALLP{});
-    if (NT * KU > 1) dma_proj(KU > 1 ? 0 : 1, KU > 1 ? 1 : 0, 1, ALLP{});
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // x rows, ctx fragments, tiles 0 and 1
-    static_for<NT * KU>([&](auto t_tag) __attribute__((always_inline)) {
-        constexpr int t = decltype(t_tag)::value, n3 = t / KU, kt = t % KU;
-        using Cur = TileDesc<K_PROJ, n3, kt>;
-        using Prev = std::conditional_t<t == 0, NoTile, TileDesc<K_PROJ, (t - 1) / KU, (t - 1) % KU>>;
-        // tile t+2: still out-projection, or the first up-projection tiles of chunk 0
-        auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
-            constexpr int t2 = t + 2;
-            if constexpr (t2 < NT * KU) dma_proj(t2 / KU, t2 % KU, s2, pc);
-            else dma_up(0, t2 - NT * KU, s2, pc);                 // up-projection tiles 0, 1 of chunk 0 (NT >= 2), see below
+    // interval p: tiles (n3, kt = 2 q) in ringU[slot] and (n3, 2 q + 1) in ringD[slot], n3 = p / NT, q = p % NT; a wave
+    // multiplies row blocks 2 role, 2 role + 1 of both.  U waves request the ringU tiles, D waves the ringD tiles.
+    auto proj_request = [&](int p, int s) __attribute__((always_inline)) {
+        const int n3 = p / NT, q = p % NT;
+        if (role == 0) dma_proj(n3, 2 * q, ldsU + s * LT_TILE);
+        else dma_proj(n3, 2 * q + 1, ldsD + s * LT_TILE);
+    };
+    proj_request(0, 0);
+    proj_request(1, 1);
+    LT_STAMP(tlU, 384);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // parameters, x, ctx fragments, intervals 0 and 1
+    LT_STAMP(tlU, 385);
+#pragma unroll
+    for (int b = 0; b < NBH; ++b)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4 bv = *(const f32x4 *)(cbo + (b >> 1) * 128 + role * 64 + (b & 1) * 32 + 8 * gq + 4 * hi);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) accp[b][4 * gq + e] = (float)xv[b][gq][e] + bv[e];
+        }
+#pragma unroll
+    for (int b = 0; b < NBH; ++b) asm volatile("" : "+v"(accp[b]));     // (made here: left alone the compiler keeps x alive and converts it block by block)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // lgkmcnt(0), visible to the compiler (see the note in U's branch)
+    static_for<P>([&](auto p_tag) __attribute__((always_inline)) {
+        constexpr int p = decltype(p_tag)::value, n3 = p / NT, q = p % NT, p2 = p + 2;
+        const unsigned bA = aR + (unsigned)(slot * LT_TILE + role * 8192), bB = bA + 3 * LT_TILE;
+        f16x8 Fa[4], Fb[4];
+        // group = two k-steps x the wave's two row blocks
+        auto rd = [&](unsigned base, int g2, f16x8 (&F)[4]) __attribute__((always_inline)) {
+            const unsigned a0 = base ^ (unsigned)((2 * g2) << 5), a1 = base ^ (unsigned)((2 * g2 + 1) << 5);
+            F[0] = frag_read<0>(a0); F[1] = frag_read<4096>(a0);
+            F[2] = frag_read<0>(a1); F[3] = frag_read<4096>(a1);
         };
-        interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
+        auto mm = [&](f16x8 (&F)[4], int ks) __attribute__((always_inline)) {      // ks = first ctx k-step of the group
+            accp[n3 * 2 + 0] = mfma16(F[0], bf[ks], accp[n3 * 2 + 0]);
+            accp[n3 * 2 + 1] = mfma16(F[1], bf[ks], accp[n3 * 2 + 1]);
+            accp[n3 * 2 + 0] = mfma16(F[2], bf[ks + 1], accp[n3 * 2 + 0]);
+            accp[n3 * 2 + 1] = mfma16(F[3], bf[ks + 1], accp[n3 * 2 + 1]);
+        };
+        if constexpr (LT_ABLATE & 64) {
+            const int s2 = slot_plus2();
+            if constexpr (p2 < P) proj_request(p2, s2);
+            else if (role == 1) dma_up(0, p2 - P, up_offset(), ldsU + s2 * LT_TILE);
+            pre_close();
+            if (p2 < P || role == 1) close_interval<4>(); else close_interval<0>();
+            next_slot();
+            return;
+        }
+        rd(bA, 0, Fa);
+        rd(bA, 1, Fb);
+        {   // requests for interval p + 2 (out-projection, or U's first two up-projection tiles)
+            const int s2 = slot_plus2();
+            if constexpr (p2 < P) proj_request(p2, s2);
+            else if (role == 1) dma_up(0, p2 - P, up_offset(), ldsU + s2 * LT_TILE);
+        }
+        wait_frags<4>(Fa);
+        mm(Fa, 8 * q + 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(bB, 0, Fa);
+        wait_frags<4>(Fb);
+        mm(Fb, 8 * q + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(bB, 1, Fb);
+        wait_frags<4>(Fa);
+        mm(Fa, 8 * q + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags<0>(Fb);
+        mm(Fb, 8 * q + 6);
+        __builtin_amdgcn_sched_barrier(0);
+        pre_close();
+        if (p2 < P || role == 1) close_interval<4>(); else close_interval<0>();
+        next_slot();
     });
-    drain(TileDesc<K_PROJ, NT - 1, KU - 1>{});
 
-    // ================================ LayerNorm 1 (wave-local) -> y fragments in S ================================
-    // (the epilogues use opaque copies of the lane ids: otherwise their address arithmetic is computed at kernel start
-    // and carried through the tile loop in registers the loop needs)
+    LT_STAMP(tlU, 386); LT_STAMP(tlD, 396);
+    // ================================ LayerNorm 1 ================================
+    // own half of the features summed here, the partner's through ST; then each role normalises its half into f16 fragments:
+    // yh[4 n3 + m] is k-step 8 n3 + 4 role + m of the up-projection (registers 8 s .. 8 s + 7 of own block b = 2 n3 + (m >> 1),
+    // s = m & 1).  D's half crosses to U through ringD (U needs all of y as B fragments); U's half crosses to D at the END
+    // (D adds the residual to the accumulator blocks of U's features in front of LayerNorm 2), when LDS and D's registers are free.
+    float ln_rstd, ln_nmr;
     {
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int l31 = lane_e & 31, hi = lane_e >> 5, lane = lane_e;
-        // one pass over the accumulators for both moments (mean, E[v^2]); a second pass normalises with a per-feature
-        // scale and offset.  (A wave alone on its SIMD pays every VALU instruction at full price: the three-pass
-        // textbook form cost 7 us per LayerNorm.)  var = E[v^2] - mean^2 in f32: the inputs are O(1) with |mean| < std.
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int n = 0; n < NB; ++n)
+        for (int b = 0; b < ((LT_ABLATE & 32) ? 0 : NBH); ++b)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int c = 4 * n + gq, f0 = 32 * n + 8 * gq + 4 * hi;
-                const f32x4 bv = *(const f32x4 *)(cbo + f0);
-                const f16x4 xv = *(const f16x4 *)(S + (c * 32 + ((l31 + c) & 31)) * 16 + hi * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = acc2[n][4 * gq + e] + bv[e] + (float)xv[e];
-                    acc2[n][4 * gq + e] = v;
-                    s1 += v;
-                    s2 = __builtin_fmaf(v, v, s2);
-                }
-            }
+            for (int r = 0; r < 16; ++r) { s1 += accp[b][r]; s2 = __builtin_fmaf(accp[b][r], accp[b][r], s2); }
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
+        if (hi == 0) *(f32x2 *)(ST + wave * 64 + l31 * 2) = f32x2{s1, s2};
+        LT_STAMP(tlU, 387); LT_STAMP(tlD, 397);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LT_STAMP(tlU, 388);
+        const f32x2 o = *(const f32x2 *)(ST + (wave ^ 4) * 64 + l31 * 2);
+        s1 += o[0]; s2 += o[1];
         const float mean = s1 * (1.0f / H);
         const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f), nmr = -mean * rstd;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // every x read of the wave is done before S is rewritten
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                f16x8 o;
-#pragma unroll
-                for (int hq = 0; hq < 2; ++hq) {
-                    const int f0 = 32 * n + 16 * s + 8 * hq + 4 * hi;              // registers 8s + 4hq + 0..3
-                    const f32x4 gv = *(const f32x4 *)(cg1 + f0), bv = *(const f32x4 *)(cbe1 + f0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 8 * s + 4 * hq + e;
-                        // g * ((v - mean) * rstd) + b  =  v * (g * rstd) + (g * (-mean * rstd) + b)
-                        o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][r], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
-                        acc2[n][r] = 0.f;
-                    }
-                }
-                *(f16x8 *)(S + (2 * n + s) * 1024 + lane * 16) = o;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // y is read back by hand-issued reads of this wave
+        ln_rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+        ln_rstd = ln_rstd * (1.5f - 0.5f * (var + 1e-5f) * ln_rstd * ln_rstd);       // one Newton step: 1 ulp of 1 / sqrt
+        ln_nmr = -mean * ln_rstd;
     }
-
-    // ================================ feed-forward ================================
-    auto refresh_lane_values = [&]() __attribute__((always_inline)) {
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        lane_offsets(lane_e);
-        const int l31e = lane_e & 31, hie = lane_e >> 5;
-        aA0 = lds_addr(ring) + off64(l31e, hie);
-        aU0 = lds_addr(ring) + l31e * 256 + ((hie ^ (l31e & 15)) << 4);
-        aY = lds_addr(S) + lane_e * 16;
-        aB = lds_addr(cb1) + hie * 16;
-    };
-    refresh_lane_values();
+    // own block b -> fragments y0 (registers 0..7), y1 (8..15); the eight parameter reads of a block are in flight together
+    auto normalise_block = [&](auto b_tag, f16x8 &y0, f16x8 &y1) __attribute__((always_inline)) {
+        constexpr int b = decltype(b_tag)::value;
+        const int f0 = (b >> 1) * 128 + role * 64 + (b & 1) * 32 + 4 * hi;
+        if constexpr (LT_ABLATE & 32) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+            for (int e = 0; e < 8; ++e) { y0[e] = (_Float16)accp[b][e]; y1[e] = (_Float16)accp[b][8 + e]; }
+            return;
+        }
+        f32x4 gv[4], bv[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)          // register r of block fb = feature 32 fb + (r & 3) + 8 (r >> 2) + 4 hi of the chunk
-            accU[fb][r] = LT_BIASINIT ? cb1[32 * fb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] : 0.f;
+        for (int gq = 0; gq < 4; ++gq) { gv[gq] = *(const f32x4 *)(cg1 + f0 + 8 * gq); bv[gq] = *(const f32x4 *)(cbe1 + f0 + 8 * gq); }
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+        for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[pp][j] = (f16x8)(_Float16)0;
-    // stream order (NT tiles per stage):
-    //     UP(0) | gelu(0) | UP(1) | DOWN(0)+gelu(1) | UP(2) | DOWN(1)+gelu(2) | ... | UP(NC-1) | DOWN(NC-2)+gelu(NC-1) | DOWN(NC-1)
-    // the GELU of chunk c+1 is VALU filler behind the MFMAs of DOWN(c); only gelu(0) is exposed.  One set of up-
-    // projection accumulators, two GELU'ed chunks (g[c & 1]).  NT >= 2 and NC >= 2.
-    // ---- UP(0)  (its first two tiles were requested by the last out-projection intervals)
-    static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
-        constexpr int j = decltype(j_tag)::value;
-        using Cur = TileDesc<K_UP, 0, j>;
-        using Prev = std::conditional_t<j == 0, NoTile, TileDesc<K_UP, 0, j - 1>>;
-        auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
-            constexpr int j2 = j + 2;
-            if constexpr (j2 < NT) dma_up(0, j2, s2, pc); else dma_up(1, j2 - NT, s2, pc);
-        };
-        interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
-    });
-    drain(TileDesc<K_UP, 0, NT - 1>{});
-    static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
-        static_for<4>([&](auto p_tag) __attribute__((always_inline)) {
-            gelu_pair(std::integral_constant<int, (LT_GROLE < 0 ? 0 : (LT_GROLE ^ 1))>{}, j_tag, p_tag, *(const f32x2 *)(cb1 + (LT_BIASINIT ? 64 : 0) + bias_off(decltype(j_tag)::value, decltype(p_tag)::value) + 4 * hi));
-        });
-    });
-
-    // ---- step c: UP(c+1), then DOWN(c) with gelu(c+1) as filler.  GP = c & 1 (g buffer of chunk c).
-    // FIRST: c == 0; LAST: c == NC - 2 (no UP(c+2) to request: a separate instantiation keeps the requests branch-free)
-    auto step = [&](auto gp_tag, auto first_tag, auto last_tag, int c) __attribute__((always_inline)) {
-        constexpr int GPT = decltype(gp_tag)::value;
-        constexpr int GP = LT_GROLE < 0 ? GPT : LT_GROLE;          // buffer DOWN(c) reads
-        constexpr int GW = GP ^ 1;                                  // buffer gelu(c+1) is written to
-        constexpr int GE = LT_GROLE < 0 ? GP ^ 1 : GP;              // buffer the tile owed on entry (of DOWN(c-1)) reads
-        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-        // fixed roles: chunk c, written to g[GW] during the previous step, moves to g[GP] behind the last owed MFMA
-        auto move_chunk = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[GP][j] = g[GW][j];
-        };
-        if constexpr (LT_GROLE >= 0 && FIRST) move_chunk();
-        auto after_owed = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
-            if constexpr (LT_GROLE >= 0 && decltype(grp_tag)::value == 0 && decltype(k_tag)::value == 7) move_chunk();
-        };
-        static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
-            constexpr int j = decltype(j_tag)::value;
-            using Cur = TileDesc<K_UP, 0, j>;
-            // owed on entry: nothing after the exposed gelu(0), else the last tile of DOWN(c-1)
-            using Entry = std::conditional_t<FIRST, NoTile, TileDesc<K_DOWN, GE, NT - 1>>;
-            using Prev = std::conditional_t<j == 0, Entry, TileDesc<K_UP, 0, j - 1>>;
-            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
-                constexpr int j2 = j + 2;
-                if constexpr (j2 < NT) dma_up(c + 1, j2, s2, pc); else dma_down(c, j2 - NT, s2, pc);
-            };
-            if constexpr (j == 0 && !FIRST) interval(Cur{}, Prev{}, VM4{}, pf, after_owed, nothing1, nothing1);
-            else interval(Cur{}, Prev{}, VM4{}, pf, nothing, nothing1, nothing1);
-        });
-        static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
-            constexpr int d = decltype(d_tag)::value;
-            using Cur = TileDesc<K_DOWN, GP, d>;
-            using Prev = std::conditional_t<d == 0, TileDesc<K_UP, 0, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
-            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
-                constexpr int d2 = d + 2;
-                if constexpr (d2 < NT) dma_down(c, d2, s2, pc);
-                else if constexpr (!LAST) dma_up(c + 2, d2 - NT, s2, pc);
-                else dma_down(c + 1, d2 - NT, s2, pc);        // chunk c+1 is the last one: only its DOWN tiles are left
-            };
-            // the 16 element pairs of gelu(c+1) behind the MFMAs of the NT intervals (lt_pair_of); their biases are read
-            // by hand one group of 8 MFMA slots ahead
-            f32x2 Bv[2][6];
-            const unsigned aBc = aB + (unsigned)(c + 1 + LT_BIASINIT) * 256u;      // (LT_BIASINIT: one chunk past the end in the last step, never used)
-            auto pre = [&](auto grp_tag) __attribute__((always_inline)) {
-                constexpr int grp = decltype(grp_tag)::value;
-                static_for<8>([&](auto k_tag) __attribute__((always_inline)) {
-                    constexpr int k = decltype(k_tag)::value, q = lt_pair_of<NT>(d, grp * 8 + k);
-                    if constexpr (q >= 0) Bv[grp][lt_pair_rank<NT>(d, grp, k)] = lds_read_b64_u<bias_off(q / 4, q % 4) * 4>(aBc);
-                });
-            };
-            auto fence = [&](auto grp_tag) __attribute__((always_inline)) {
-                constexpr int grp = decltype(grp_tag)::value;
-                bias_fence_n<lt_pair_rank<NT>(d, grp, 8), grp == 0>(Bv[grp]);
-            };
-            auto fill = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
-                constexpr int grp = decltype(grp_tag)::value, k = decltype(k_tag)::value, q = lt_pair_of<NT>(d, grp * 8 + k);
-                if constexpr (q >= 0 && !((LT_ABLATE & 32) && q >= 10) && !(LT_ABLATE & 64))
-                    gelu_pair(std::integral_constant<int, GW>{}, std::integral_constant<int, q / 4>{},
-                              std::integral_constant<int, q % 4>{}, Bv[grp][lt_pair_rank<NT>(d, grp, k)]);
-            };
-            interval(Cur{}, Prev{}, VM4{}, pf, fill, pre, fence);
-        });
-    };
-    // NC is even and >= 4: steps c = 0 .. NC-2 (GP = c & 1), the last one with GP = 0
-    step(H0{}, std::true_type{}, std::false_type{}, 0);
-#if LT_GROLE >= 0
-    // fixed roles: one copy of the step in the loop
-    for (int c = 1; c + 2 < NC; ++c) step(H1{}, std::false_type{}, std::false_type{}, c);
-#else
-    for (int c = 1; c + 3 < NC; c += 2) {
-        step(H1{}, std::false_type{}, std::false_type{}, c);
-        step(H0{}, std::false_type{}, std::false_type{}, c + 1);
-    }
-    step(H1{}, std::false_type{}, std::false_type{}, NC - 3);
-#endif
-    step(H0{}, std::false_type{}, std::true_type{}, NC - 2);
-    // ---- DOWN(NC-1)
-    auto last_down = [&](auto gp_tag) __attribute__((always_inline)) {
-        constexpr int GP = LT_GROLE < 0 ? decltype(gp_tag)::value : LT_GROLE;
-        constexpr int GE = LT_GROLE < 0 ? GP ^ 1 : GP;
-        auto after_owed = [&](auto grp_tag, auto k_tag) __attribute__((always_inline)) {
-            if constexpr (LT_GROLE >= 0 && decltype(grp_tag)::value == 0 && decltype(k_tag)::value == 7) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[GP][j] = g[GP ^ 1][j];
+            for (int e = 0; e < 4; ++e) {
+                // g * ((v - mean) * rstd) + b  =  v * (g * rstd) + (g * (-mean * rstd) + b)
+                const _Float16 y = (_Float16)__builtin_fmaf(accp[b][4 * gq + e], gv[gq][e] * ln_rstd, __builtin_fmaf(gv[gq][e], ln_nmr, bv[gq][e]));
+                if (gq < 2) y0[4 * gq + e] = y; else y1[4 * (gq - 2) + e] = y;
             }
-        };
-        static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
-            constexpr int d = decltype(d_tag)::value;
-            using Cur = TileDesc<K_DOWN, GP, d>;
-            using Prev = std::conditional_t<d == 0, TileDesc<K_DOWN, GE, NT - 1>, TileDesc<K_DOWN, GP, d - 1>>;
-            auto pf = [&](int s2, auto pc) __attribute__((always_inline)) {
-                constexpr int d2 = d + 2;
-                if constexpr (d2 < NT) dma_down(NC - 1, d2, s2, pc);
-            };
-            constexpr int vm = d + 2 < NT ? 4 : 0;
-            if constexpr (d == 0) interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, after_owed, nothing1, nothing1);
-            else interval(Cur{}, Prev{}, std::integral_constant<int, vm>{}, pf, nothing, nothing1, nothing1);
-        });
-        drain(TileDesc<K_DOWN, GP, NT - 1>{});
+        asm volatile("" ::: "memory");                        // (one block's parameters at a time: unfenced, the loads of all blocks are hoisted to the front)
     };
-    last_down(H1{});                                          // NC - 1 is odd
+    // the exchange areas: pair t owns NYH KiB, fragment m of lane l at m KiB + 16 l
+    char *const xch = ringD + t * (NYH * 1024) + lane * 16;    // LayerNorm 1: D's half (ringD is idle until D's first requests)
+    LT_STAMP(tlU, 389); LT_STAMP(tlD, 399);
 
-    // ================================ LayerNorm 2 (wave-local) -> rows in S -> HBM ================================
-    TL_STAMP(tl++);
-    {
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        const int hi = lane_e >> 5, lane = lane_e;
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f16x8 yv = *(const f16x8 *)(S + (2 * n + s) * 1024 + lane * 16);
-#pragma unroll
-                for (int hq = 0; hq < 2; ++hq) {
-                    const f32x4 bv = *(const f32x4 *)(cb2 + 32 * n + 16 * s + 8 * hq + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 8 * s + 4 * hq + e;
-                        const float v = acc2[n][r] + bv[e] + (float)yv[4 * hq + e];
-                        acc2[n][r] = v;
-                        s1 += v;
-                        s2 = __builtin_fmaf(v, v, s2);
-                    }
-                }
-            }
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        const float mean = s1 * (1.0f / H);
-        const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
-        const float rstd = 1.0f / sqrtf(var + 1e-5f), nmr = -mean * rstd;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // fragment (q, lane) -> position (lane + 2q) & 63 of row q: the row-major read below is conflict-free
-#pragma unroll
-        for (int n = 0; n < NB; ++n)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int q = 2 * n + s;
-                f16x8 o;
-#pragma unroll
-                for (int hq = 0; hq < 2; ++hq) {
-                    const int f0 = 32 * n + 16 * s + 8 * hq + 4 * hi;
-                    const f32x4 gv = *(const f32x4 *)(cg2 + f0), bv = *(const f32x4 *)(cbe2 + f0);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][8 * s + 4 * hq + e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
-                }
-                *(f16x8 *)(S + q * 1024 + ((lane + 2 * q) & 63) * 16) = o;
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        TL_STAMP(tl++);
+    // ================================ rows -> HBM (both waves of the pair, alternate 1 KiB pieces) ================================
+    // (called at the end of EACH role's branch, which then returns: with a common tail behind the branches the register
+    // allocator carries U's fragments "through" D's branch — stores in front of D's loop, dead reloads behind it)
+    auto store_rows = [&]() __attribute__((always_inline)) {
+        LT_STAMP(tlU, 394);
+        const char *S = smem + t * (64 * H);
+        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         // 16-byte unit (token, 8-feature chunk c8) of the output = bytes h2*8.. of the fragments (q, token) and
         // (q, token + 32), q = c8 >> 1, h2 = c8 & 1
         half_t *ow = a.out + (size_t)tok_w * H;
 #pragma unroll
-        for (int st = 0; st < H / 16; ++st) {
+        for (int st2 = 0; st2 < H / 32; ++st2) {
+            const int st = 2 * st2 + role;
             const int v = st * 64 + lane, tok = v / (H / 8), c8 = v - tok * (H / 8), q = c8 >> 1, h2 = c8 & 1;
             const char *row = S + q * 1024 + h2 * 8;
             const f16x4 lo = *(const f16x4 *)(row + ((tok + 2 * q) & 63) * 16);
@@ -677,11 +416,391 @@ __global__ __launch_bounds__(256, 1) void layer_tail_kernel(TailArgs a) {
             for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi4[e]; }
             *(f16x8 *)(ow + (size_t)tok * H + c8 * 8) = o;
         }
-    }
 #ifdef BERT_HIP_TIMELINE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TL_STAMP(tl++);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LT_STAMP(tlU, 395);
 #endif
+    };
+
+    if (role == 0) {
+        // =====================================================================================================
+        // U: y fragments of all k-steps, up-projection, GELU
+        // =====================================================================================================
+        f16x8 Y[NQ];
+        static_for<NBH>([&](auto b_tag) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_tag)::value;             // own block b = k-steps 8 (b >> 1) + 2 (b & 1), + 1
+            normalise_block(b_tag, Y[8 * (b >> 1) + 2 * (b & 1)], Y[8 * (b >> 1) + 2 * (b & 1) + 1]);
+        });
+        LT_STAMP(tlU, 390);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // [B2] D's half is in LDS
+        LT_STAMP(tlU, 391);
+#pragma unroll
+        for (int m = 0; m < NYH; ++m) Y[8 * (m >> 2) + 4 + (m & 3)] = *(const f16x8 *)(xch + m * 1024);
+        // (a wait the COMPILER sees: its own bookkeeping of these loads would otherwise stay "pending" around the loop's back
+        // edge — the waits inside asm statements are invisible to it — and it would add lgkmcnt waits in front of every MFMA
+        // that reads y, draining the hand-issued fragment reads each time)
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0)
+        LT_STAMP(tlU, 392);
+        // two sets of up-projection accumulators (chunk parity), initial value = the chunk's bias
+        f32x16 accU[2][2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)          // register r of block fb = feature 32 fb + (r & 3) + 8 (r >> 2) + 4 hi of the chunk
+                    accU[pp][fb][r] = cb1[pp * 64 + 32 * fb + (r & 3) + 8 * (r >> 2) + 4 * hi];
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0), visible to the compiler (see above)
+        f16x8 Fc[4];                                          // the fragment group carried across the barrier
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Fc[j] = (f16x8)(_Float16)0;
+        const unsigned aB = lds_addr(cb1) + hi * 16;          // up-projection biases of a lane's features: + chunk * 256 B
+        char *const Gw = G + t * 8192 + lane * 16;            // + parity * 4096 + fragment * 1024
+
+        // GELU of fragment jf of the chunk in accumulator set PG (features 32 (jf >> 1) + 16 (jf & 1) .. + 16 = registers
+        // 8 s .. 8 s + 7 of block jf >> 1), as ONE batch of four element pairs: a pair is a chain of ten dependent instructions
+        // (two quarter-rate transcendentals twice), and an in-order wave that runs the pairs one behind the other, each
+        // between two of its MFMAs, pays the whole chain every time (250-350 cycles per pair, measured with stamps);
+        // four chains side by side hide each other's latency.  The result is the down-projection's B fragment: published at
+        // once (D reads it behind the barrier that closes the chunk's last GELU interval); the accumulators restart from the
+        // bias of the chunk two ahead (b0: elements 0..3 of the fragment, b1: 4..7).
+        auto gelu_pair = [&](auto pg_tag, auto jf_tag, auto p_tag, const f32x4 &b0, const f32x4 &b1, f16x8 &o) __attribute__((always_inline)) {
+            constexpr int PG = decltype(pg_tag)::value, jf = decltype(jf_tag)::value, fb = jf >> 1, s8 = 8 * (jf & 1), p = decltype(p_tag)::value;
+            const float x0 = accU[PG][fb][s8 + 2 * p], x1 = accU[PG][fb][s8 + 2 * p + 1];
+            if constexpr (LT_ABLATE & 2) {
+                o[2 * p] = (_Float16)x0; o[2 * p + 1] = (_Float16)x1;
+            } else {
+                const f16x2_t gv = gelu_pk16(x0, x1);
+                o[2 * p] = gv[0]; o[2 * p + 1] = gv[1];
+            }
+            accU[PG][fb][s8 + 2 * p] = p < 2 ? b0[2 * p] : b1[2 * p - 4];
+            accU[PG][fb][s8 + 2 * p + 1] = p < 2 ? b0[2 * p + 1] : b1[2 * p - 3];
+            if constexpr (p == 3 && !(LT_ABLATE & 16)) *(f16x8 *)(Gw + PG * 4096 + jf * 1024) = o;
+        };
+        // fragments of GELU interval jg: fstart(jg) .. fstart(jg + 1) - 1 of 4
+        auto fstart = [](int jg) constexpr { return (4 * jg + NG - 1) / NG; };
+        constexpr int MAXF = (4 + NG - 1) / NG;
+
+        // One interval of U.  C_PAR: parity of chunk c (accumulator set of UP(c)); MMA: UP tile (c, j) exists; GELU: chunk c-1
+        // exists and fragments fstart(j) .. of it are GELU'ed between this interval's MFMAs; CARRY: the last group of the
+        // previous tile is owed.
+        auto u_interval = [&](auto par_tag, auto j_tag, auto mma_tag, auto gelu_tag, auto carry_tag, int c) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_tag)::value, j = decltype(j_tag)::value;
+            constexpr bool MMA = decltype(mma_tag)::value, GELU = decltype(gelu_tag)::value, CARRY = decltype(carry_tag)::value;
+            constexpr int f0 = GELU ? fstart(j) : 0, nf = GELU ? fstart(j + 1) - fstart(j) : 0;
+            constexpr int PG = PAR ^ 1;                                           // accumulator set of chunk c - 1
+            f16x8 Fa[4], Fb[4];
+            [[maybe_unused]] const bool fine = tlU && tl >= 40 && tl < 46;                 // (timeline builds: stamps inside six intervals)
+            [[maybe_unused]] const int fb0 = 402 + (tl - 40) * 10;
+            LT_STAMP_FINE(fine, fb0 + 0);
+            unsigned bU = aUp + (unsigned)(slot * LT_TILE);
+            asm volatile("" : "+v"(bU));                                          // (made here, not kept per slot)
+            // group g4 = k-steps 2 g4, 2 g4 + 1 x both row blocks
+            auto rd = [&](int g4, f16x8 (&F)[4]) __attribute__((always_inline)) {
+                unsigned a0 = bU ^ (unsigned)((2 * g4) << 5), a1 = bU ^ (unsigned)((2 * g4 + 1) << 5);
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                F[0] = frag_read<0>(a0); F[1] = frag_read<8192>(a0);
+                F[2] = frag_read<0>(a1); F[3] = frag_read<8192>(a1);
+            };
+            // biases of this interval's fragments (of the chunk two ahead of the one being GELU'ed = c + 1), by hand, first in the
+            // queue: the wait for the first fragment group retires them too
+            f32x4 Bv[MAXF][2];
+            if constexpr (GELU) {
+                const unsigned aBc = aB + (unsigned)(c + 1) * 256u;
+                static_for<nf>([&](auto k_tag) __attribute__((always_inline)) {
+                    constexpr int k = decltype(k_tag)::value, jf = f0 + k, off = 4 * (32 * (jf >> 1) + 16 * (jf & 1));
+                    Bv[k][0] = lds_read_f32x4_h<off>(aBc);
+                    Bv[k][1] = lds_read_f32x4_h<off + 32>(aBc);
+                });
+            }
+            if constexpr (MMA) { rd(0, Fa); rd(1, Fb); }
+            LT_STAMP_FINE(fine, fb0 + 1);
+            // pair q (0 .. 4 nf - 1; fragment q / 4, pair q % 4) rides behind this wave's MFMA slot gslot(q) of the interval (4 carried,
+            // then 12 own).  LT_GELU_BATCH: the four pairs of a fragment together behind the last MFMA of a group (their ten-deep
+            // dependency chains side by side), else spread evenly over the own MFMAs
+            f16x8 og[MAXF];
+            auto gslot = [](int q) constexpr { return LT_GELU_BATCH ? 7 + 4 * (q / 4) : 4 + (q * 12) / (4 * (nf > 0 ? nf : 1)); };
+            auto fill = [&](auto slot_tag) __attribute__((always_inline)) {
+                constexpr int sl = decltype(slot_tag)::value;
+                static_for<4 * nf>([&](auto q_tag) __attribute__((always_inline)) {
+                    constexpr int q = decltype(q_tag)::value, k = q / 4;
+                    if constexpr (gslot(q) == sl)
+                        gelu_pair(std::integral_constant<int, PG>{}, std::integral_constant<int, f0 + k>{}, std::integral_constant<int, q % 4>{}, Bv[k][0], Bv[k][1], og[k]);
+                });
+            };
+            // the carried group: k-steps 6, 7 of the previous tile (jp) into the accumulator set of ITS chunk
+            if constexpr (CARRY) {
+                constexpr int jp = j == 0 ? NT - 1 : j - 1, PC = j == 0 ? PAR ^ 1 : PAR;
+                accU[PC][0] = mfma16(Fc[0], Y[8 * jp + 6], accU[PC][0]);
+                accU[PC][1] = mfma16(Fc[1], Y[8 * jp + 6], accU[PC][1]);
+                accU[PC][0] = mfma16(Fc[2], Y[8 * jp + 7], accU[PC][0]);
+                accU[PC][1] = mfma16(Fc[3], Y[8 * jp + 7], accU[PC][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                LT_STAMP_FINE(fine, fb0 + 2);
+            }
+            auto mm = [&](f16x8 (&F)[4], auto g4_tag) __attribute__((always_inline)) {
+                constexpr int g4 = decltype(g4_tag)::value, sb = 4 + 4 * g4;
+                accU[PAR][0] = mfma16(F[0], Y[8 * j + 2 * g4], accU[PAR][0]);
+                fill(std::integral_constant<int, sb + 0>{});
+                accU[PAR][1] = mfma16(F[1], Y[8 * j + 2 * g4], accU[PAR][1]);
+                fill(std::integral_constant<int, sb + 1>{});
+                accU[PAR][0] = mfma16(F[2], Y[8 * j + 2 * g4 + 1], accU[PAR][0]);
+                fill(std::integral_constant<int, sb + 2>{});
+                accU[PAR][1] = mfma16(F[3], Y[8 * j + 2 * g4 + 1], accU[PAR][1]);
+                fill(std::integral_constant<int, sb + 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto bias_landed = [&]() __attribute__((always_inline)) {
+                static_for<nf>([&](auto k_tag) __attribute__((always_inline)) { landed(Bv[decltype(k_tag)::value][0]); landed(Bv[decltype(k_tag)::value][1]); });
+            };
+            using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+            if constexpr (MMA) {
+                // (the first own group's wait retires the bias reads too; by then the carried MFMAs, which in a chunk's first
+                // interval still write the accumulator set being read, are through)
+                wait_frags<4>(Fa);
+                bias_landed();
+                LT_STAMP_FINE(fine, fb0 + 3);
+                mm(Fa, I0{});
+                LT_STAMP_FINE(fine, fb0 + 4);
+                rd(2, Fa);
+                wait_frags<4>(Fb);
+                LT_STAMP_FINE(fine, fb0 + 5);
+                mm(Fb, I1{});
+                LT_STAMP_FINE(fine, fb0 + 6);
+                rd(3, Fc);
+                wait_frags<4>(Fa);
+                LT_STAMP_FINE(fine, fb0 + 7);
+                mm(Fa, I2{});
+                LT_STAMP_FINE(fine, fb0 + 8);
+            } else {
+                wait_lgkm<0>();
+                bias_landed();
+                static_for<12>([&](auto s_tag) __attribute__((always_inline)) { fill(std::integral_constant<int, 4 + decltype(s_tag)::value>{}); });
+            }
+            static_assert(MAXF <= 2, "two GELU batches per interval at most");
+            pre_close();
+            if constexpr (MMA) close_interval<0>(Fc); else close_interval<0>();
+            next_slot();
+        };
+        using TT = std::true_type; using FF = std::false_type;
+        LT_STAMP(tlU, 393);
+        __builtin_amdgcn_s_setprio(LT_UPRIO);                 // U's stream is the longer one: it wins the arbitration for the SIMD
+        // chunk c: UP(c) with gelu(c - 1) as filler
+        auto u_chunk = [&](auto par_tag, auto first_tag, int c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;            // c == 0
+            static_for<NT>([&](auto j_tag) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_tag)::value;
+                constexpr bool carry = !(FIRST && j == 0), gelu = !FIRST && j < NG;
+                u_interval(par_tag, j_tag, TT{}, std::integral_constant<bool, gelu>{}, std::integral_constant<bool, carry>{}, c);
+            });
+        };
+        u_chunk(std::integral_constant<int, 0>{}, TT{}, 0);
+        for (int c = 1; c + 1 < NC; c += 2) {
+            u_chunk(std::integral_constant<int, 1>{}, FF{}, c);
+            u_chunk(std::integral_constant<int, 0>{}, FF{}, c + 1);
+        }
+        u_chunk(std::integral_constant<int, 1>{}, FF{}, NC - 1);
+        // tail: the carried group of the last tile, gelu(NC - 1) (parity of "chunk NC" = 0), then idle barriers
+        static_for<LAGT>([&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            if constexpr (k < NG)
+                u_interval(std::integral_constant<int, 0>{}, std::integral_constant<int, k>{}, FF{}, TT{}, std::integral_constant<bool, k == 0>{}, NC);
+            else {
+                // first idle interval: this wave's half of y (the residual of its features) goes to ringU (idle since its last
+                // tile: pair t owns NYH KiB like above); D adds it in front of LayerNorm 2
+                if constexpr (k == NG) {
+                    char *const xu = ringU + t * (NYH * 1024) + lane * 16;
+#pragma unroll
+                    for (int m = 0; m < NYH; ++m) *(f16x8 *)(xu + m * 1024) = Y[8 * (m >> 2) + (m & 3)];
+                }
+                pre_close(); close_interval<0>(); next_slot();
+            }
+        });
+        static_assert(LAGT > NG, "U needs an idle interval to hand its half of y over");
+        // LayerNorm 2 is D's; U stores half of the rows below
+        asm volatile("s_barrier" ::: "memory");                                   // [E0] every D wave has taken U's half of y in
+        asm volatile("s_barrier" ::: "memory");                                   // [E1] D's rows are staged
+        store_rows();
+        return;
+    } else {
+        // =====================================================================================================
+        // D: all output accumulators, down-projection
+        // =====================================================================================================
+        // accumulators start from b2 (+ y, the residual, for D's own features: blocks ob = 2, 3 of every n3; U's half of y is
+        // added at the end): block n = 4 n3 + ob holds features 32 n + 8 (r >> 2) + 4 hi + (r & 3)
+        f16x8 yh[NYH];
+        static_for<NBH>([&](auto b_tag) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_tag)::value;
+            normalise_block(b_tag, yh[2 * b], yh[2 * b + 1]);
+            *(f16x8 *)(xch + (2 * b) * 1024) = yh[2 * b];
+            *(f16x8 *)(xch + (2 * b + 1) * 1024) = yh[2 * b + 1];
+        });
+        LT_STAMP(tlD, 400);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");          // [B2] D's half is in LDS
+        // (in this order: the 96 out-projection accumulators are dead before the 192 of the feed-forward come to life)
+        f32x16 acc2[NB];
+        static_for<NBH>([&](auto b_tag) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_tag)::value, n3 = b >> 1, obp = b & 1;
+            f32x4 bu[4], bd[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                bu[gq] = *(const f32x4 *)(cb2 + n3 * 128 + obp * 32 + 8 * gq + 4 * hi);
+                bd[gq] = *(const f32x4 *)(cb2 + n3 * 128 + 64 + obp * 32 + 8 * gq + 4 * hi);
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc2[4 * n3 + obp][4 * gq + e] = bu[gq][e];
+                    acc2[4 * n3 + 2 + obp][4 * gq + e] = (float)yh[2 * b + (gq >> 1)][4 * (gq & 1) + e] + bd[gq][e];
+                }
+            asm volatile("" ::: "memory");
+        });
+        __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0), visible to the compiler
+        // fragment groups: one k-step = the four row blocks of the weight tile + the matching B fragment of the GELU'ed chunk
+        // (re-read per tile: holding the chunk's four fragments would cost 12 registers more than the 256 there are)
+        const unsigned aD = aR + 3 * LT_TILE;                 // ringD
+        const unsigned offI = rows_offset(I);
+        auto dma_down = [&](int c, int n3, unsigned tile) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offI, I * 2, tile); };
+        const unsigned aG = lds_addr(G) + (unsigned)(t * 8192 + lane * 16);
+        // D requests EVERY feed-forward tile (U's stream is the longer one: GELU, bias reads): in feed-forward interval i the
+        // up-projection tile i + 2 (into ringU) and the down-projection tile i - LAGT + 2 (into ringD), four pieces each
+        const unsigned offU = up_offset();
+        const int NUP = NC * NT;                              // up-projection tiles (= down-projection tiles)
+        auto request = [&](auto up_tag, auto down_tag, int iu, int id) __attribute__((always_inline)) {
+            const int s2 = slot_plus2();
+            if constexpr (decltype(up_tag)::value) dma_up(iu / NT, iu % NT, offU, ldsU + s2 * LT_TILE);
+            if constexpr (decltype(down_tag)::value) dma_down(id / NT, id % NT, ldsD + s2 * LT_TILE);
+        };
+        using TT = std::true_type; using FF = std::false_type;
+        if (LT_DPRIO) __builtin_amdgcn_s_setprio(LT_DPRIO);
+        // head: LAGT intervals without a tile of its own
+        static_for<LAGT>([&](auto k_tag) __attribute__((always_inline)) {
+            constexpr int k = decltype(k_tag)::value;
+            constexpr bool dn = k >= LAGT - 2;
+            request(TT{}, std::integral_constant<bool, dn>{}, k + 2, k - (LAGT - 2));
+            // at the close the pieces of the interval before have landed: all but the newest 4 (+ 4)
+            pre_close();
+            close_interval<dn ? 8 : 4>();
+            next_slot();
+        });
+        // DOWN(c), tile d: acc2[4 d + ob] += W2(row block ob, k-step kk) x g(c)[kk].  UPQ: how many of the chunk's intervals
+        // still have an up-projection tile to request (NT, or fewer near the end); LAST: c == NC - 1
+        auto d_chunk = [&](auto upq_tag, auto last_tag, int c) __attribute__((always_inline)) {
+            constexpr int UPQ = decltype(upq_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
+                constexpr int d = decltype(d_tag)::value;
+                constexpr bool up = d < UPQ, dn = !(LAST && d + 2 >= NT);
+                f16x8 Fa[4], Fb[4], ga, gb;
+                unsigned bD = aD + (unsigned)(slot * LT_TILE), bG = aG + (unsigned)((c & 1) * 4096);
+                asm volatile("" : "+v"(bD), "+v"(bG));         // (made here, not kept per slot)
+                auto rd = [&](auto kk_tag, f16x8 (&F)[4], f16x8 &gv) __attribute__((always_inline)) {
+                    constexpr int kk = decltype(kk_tag)::value;
+                    unsigned a0 = bD ^ (unsigned)(kk << 5);
+                    asm volatile("" : "+v"(a0));
+                    F[0] = frag_read<0>(a0); F[1] = frag_read<4096>(a0); F[2] = frag_read<8192>(a0); F[3] = frag_read<12288>(a0);
+                    gv = lds_read_b128_u<kk * 1024>(bG);
+                };
+                auto wait_group = [&](auto n_tag, f16x8 (&F)[4], f16x8 &gv) __attribute__((always_inline)) {
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(F[0]), "+v"(F[1]), "+v"(F[2]), "+v"(F[3]), "+v"(gv) : "n"(decltype(n_tag)::value) : "memory");
+                };
+                auto mm = [&](f16x8 (&F)[4], const f16x8 &gv) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int ob = 0; ob < 4; ++ob) acc2[4 * d + ob] = mfma16(F[ob], gv, acc2[4 * d + ob]);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                using N5 = std::integral_constant<int, 5>; using N0 = std::integral_constant<int, 0>;
+                rd(std::integral_constant<int, 0>{}, Fa, ga);
+                rd(std::integral_constant<int, 1>{}, Fb, gb);
+                wait_group(N5{}, Fa, ga);
+                mm(Fa, ga);
+                rd(std::integral_constant<int, 2>{}, Fa, ga);
+                if constexpr (LT_DMA_SPLIT) request(std::integral_constant<bool, up>{}, FF{}, c * NT + d + LAGT + 2, 0);
+                else request(std::integral_constant<bool, up>{}, std::integral_constant<bool, dn>{}, c * NT + d + LAGT + 2, c * NT + d + 2);
+                wait_group(N5{}, Fb, gb);
+                mm(Fb, gb);
+                rd(std::integral_constant<int, 3>{}, Fb, gb);
+                if constexpr (LT_DMA_SPLIT) request(FF{}, std::integral_constant<bool, dn>{}, 0, c * NT + d + 2);
+                wait_group(N5{}, Fa, ga);
+                mm(Fa, ga);
+                wait_group(N0{}, Fb, gb);
+                mm(Fb, gb);
+                pre_close();
+                close_interval<(up ? 4 : 0) + (dn ? 4 : 0)>();
+                next_slot();
+            });
+        };
+        // up-projection tile of DOWN tile id: id + LAGT + 2 < NUP, i.e. every tile of the chunks c <= NC - 4, the first NT - 2 of
+        // chunk NC - 3 (LAGT = 2 NT), none later
+        static_assert(LAGT == 2 * NT, "the request schedule below assumes D runs two chunks behind");
+        (void)NUP;
+        for (int c = 0; c + 3 < NC; ++c) d_chunk(std::integral_constant<int, NT>{}, FF{}, c);
+        d_chunk(std::integral_constant<int, NT - 2>{}, FF{}, NC - 3);
+        d_chunk(std::integral_constant<int, 0>{}, FF{}, NC - 2);
+        d_chunk(std::integral_constant<int, 0>{}, TT{}, NC - 1);
+
+        // ================================ LayerNorm 2 (wave-local) -> rows staged in LDS ================================
+        {
+            char *S = smem + t * (64 * H);                    // 32 tokens x H halfs (the rings are idle: every wave is past its last read)
+            const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), hi = lane >> 5;   // (not kept through the loop)
+            // U's half of the residual: fragment m = 4 n3 + 2 obp + s of pair t = registers 8 s .. of block 4 n3 + obp
+            {
+                const char *const xu = ringU + t * (NYH * 1024) + lane * 16;
+#pragma unroll
+                for (int n3 = 0; n3 < NT; ++n3) {
+                    f16x8 yu[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) yu[m] = *(const f16x8 *)(xu + (4 * n3 + m) * 1024);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc2[4 * n3 + (m >> 1)][8 * (m & 1) + e] += (float)yu[m][e];
+                    asm volatile("" ::: "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // [E0] the staging below overwrites other pairs' areas
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s1 += acc2[n][r]; s2 = __builtin_fmaf(acc2[n][r], acc2[n][r], s2); }
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            const float mean = s1 * (1.0f / H);
+            const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
+            float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
+            rstd = rstd * (1.5f - 0.5f * (var + 1e-5f) * rstd * rstd);
+            const float nmr = -mean * rstd;
+            // fragment (q, lane) -> position (lane + 2q) & 63 of row q: the row-major read of the store loop is conflict-free.
+            // The eight parameter reads of a block are in flight together.
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                f32x4 gv[4], bv[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) { gv[g4] = *(const f32x4 *)(cg2 + 32 * n + 8 * g4 + 4 * hi); bv[g4] = *(const f32x4 *)(cbe2 + 32 * n + 8 * g4 + 4 * hi); }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int q = 2 * n + s;
+                    f16x8 o;
+#pragma unroll
+                    for (int hq = 0; hq < 2; ++hq)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][8 * s + 4 * hq + e], gv[2 * s + hq][e] * rstd, __builtin_fmaf(gv[2 * s + hq][e], nmr, bv[2 * s + hq][e]));
+                    *(f16x8 *)(S + q * 1024 + ((lane + 2 * q) & 63) * 16) = o;
+                }
+                asm volatile("" ::: "memory");
+            }
+            LT_STAMP(tlD, 401);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // [E1]
+        }
+        store_rows();
+    }
+}
+
+static size_t layer_tail_lds(int H, int I) {
+    return (size_t)6 * LT_TILE + 32768 + 8 * 64 * 4 + (size_t)(6 * H + I + 128) * sizeof(float);
 }
 
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2) {
@@ -689,30 +808,49 @@ bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gemm
     if (Wo.type != GW_F16 || W1.type != GW_F16 || W2.type != GW_F16 || !W1.w16p || !W2.w16p) return false;
     if (Wo.N != H || Wo.K != H || W2.N != H || W2.K != I) return false;
     if (H % 128 != 0 || H < 256 || H > 384 || I % 128 != 0 || I < 256) return false;     // an even number >= 4 of 64-feature chunks
-    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + I + 64) * sizeof(float);
-    return lds <= 160 * 1024;
+    return layer_tail_lds(H, I) <= 160 * 1024;
 }
 
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
-                       const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
-                       const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream) {
+                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
+                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream) {
     TailArgs a;
     a.ctx = ctx; a.x = x; a.wo = Wo.w16; a.w1p = W1.w16p; a.w2p = W2.w16p;
-    a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out; a.I = W1.N;
-    const int H = W1.K, NT = H / 128;
-    const size_t lds = (size_t)4 * 64 * H + 3 * LT_TILE + (size_t)(6 * H + a.I + 64) * sizeof(float);
+    a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out;
+    a.I = W1.N;
+    const int H = W1.K;
+    const size_t lds = layer_tail_lds(H, a.I);
     static bool configured[4][MAX_HIP_DEVICES] = {};
-    auto go = [&](auto kernel) __attribute__((always_inline)) {
-        if (first_launch_on_device(configured[NT])) {
+    auto go = [&](auto kernel, int nt) {
+        if (first_launch_on_device(configured[nt]))
             (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
+#ifdef BERT_HIP_TIMELINE
+        static int shots = 0;
+        if (M_pad >= 128 * 256 && shots++ == 20) {
+            (void)hipDeviceSynchronize();
+            static unsigned long long h[256 * 512];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl_tail), sizeof(h));
+            for (int b : {0, 100}) {
+                const unsigned long long *r = h + b * 512, t0 = r[0];
+                auto rel = [&](int i) { return r[i] ? (long long)(r[i] - t0) : -1LL; };
+                fprintf(stderr, "tail wg %d phases:", b);
+                for (int i = 384; i < 402; ++i) fprintf(stderr, " %d:%lld", i, rel(i));
+                fprintf(stderr, "\nt3 wg %d inside U's intervals 40..45 (start, reads issued, carried done, g0 landed, g0 done, g1 landed, g1 done, g2 landed, g2 done):", b);
+                for (int k = 0; k < 6; ++k) {
+                    fprintf(stderr, " [");
+                    for (int i = 1; i < 9; ++i) fprintf(stderr, "%lld ", r[402 + k * 10 + i] ? (long long)(r[402 + k * 10 + i] - r[402 + k * 10]) : -1LL);
+                    fprintf(stderr, "]");
+                }
+                fprintf(stderr, "\nt3 wg %d intervals (start | U arrives +, D arrives +, length):", b);
+                for (int i = 1; i < 128 && r[i]; ++i)
+                    fprintf(stderr, " [%d %lld | %lld %lld %lld]", i, rel(i - 1), (long long)(r[128 + i] - r[i - 1]), r[256 + i] ? (long long)(r[256 + i] - r[i - 1]) : -1LL, (long long)(r[i] - r[i - 1]));
+                fprintf(stderr, "\n");
+            }
         }
-        hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(256), lds, stream, a);
-        TL_DUMP(M_pad >= 128 * 256, 200);
+#endif
     };
-    switch (NT) {
-        case 2: go(layer_tail_kernel<2>); break;
-        default: go(layer_tail_kernel<3>); break;
-    }
+    if (H == 256) go(layer_tail_kernel<2>, 2); else go(layer_tail_kernel<3>, 3);
 }
 
 }  // namespace bert_hip

@@ -265,14 +265,6 @@ int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t
         if (!layer_tail_supported(wo.w, w1.w, w2.w)) return -2;
         launch_layer_tail(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
                           db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
-    } else if (impl == 3) {
-        if (!layer_tail2_supported(wo.w, w1.w, w2.w)) return -2;
-        launch_layer_tail2(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
-                           db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
-    } else if (impl == 4) {
-        if (!layer_tail3_supported(wo.w, w1.w, w2.w)) return -2;
-        launch_layer_tail3(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
-                           db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
     } else if (impl == 2) {
         if (!proj_ffn_fused_supported(wo.w, w1.w, w2.w)) return -2;
         launch_proj_ffn_fused(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),

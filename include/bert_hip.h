@@ -100,8 +100,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_ATTN          "mfma" (default) | "naive"
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
  *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
- *   BERT_HIP_TAIL          1 (default) | 0 | 2 — token-owning-waves kernel for out-projection + LN + FFN + LN (f16 weights);
- *                          2 = its wave-pair form (two waves per SIMD, layer_tail2.hip; same results up to summation order)
+ *   BERT_HIP_TAIL          1 (default) | 0 — one-launch kernel for out-projection + LN + FFN + LN (layer_tail.hip, f16 weights)
  *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernels (sentences of up to 128 tokens)
  *   BERT_HIP_QKV2          1 (default) | 0 — their second generation (windows of whole sentences, qkv_attention2.hip)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize                            */

@@ -47,7 +47,7 @@ BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t 
 /* Everything of a layer after the attention (reference bert.cpp:859-901):
  *   y = LayerNorm(ctx Wo^T + bo + x) * g1 + be1;  out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2
  * ctx, x, out [M][H] f16 bits; Wo [H][H], W1 [I][H], W2 [H][I] in file layout of `wtype`.
- * impl: 0 = GEMM + LayerNorm kernels, 1 = token-owning-waves kernel (layer_tail.hip), 2 = panel kernel
+ * impl: 0 = GEMM + LayerNorm kernels, 1 = the one-launch kernel with specialist wave pairs (layer_tail.hip), 2 = panel kernel
  * (ffn_fused.hip with the leading projection phase); -2 if the shape is not supported by the chosen kernel.   */
 BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x,
                                           const void *Wo, const void *W1, const void *W2, int32_t wtype,
