@@ -210,16 +210,14 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
                        hipStream_t s) {
     const int n_pad = (max_len + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const size_t lds = (size_t)n_pad * D * 2 + (size_t)D * (n_pad + VT_PAD) * 2;
-    static size_t configured[2][MAX_HIP_DEVICES] = {};        // per device: the opt-in is a per-device attribute
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= MAX_HIP_DEVICES - 1;
+    // per device: the opt-in is a per-device attribute; the devices of a context launch from threads of their own
+    static DeviceFlags configured[2];
     const bool wide = n_pad > 128;
-    if (lds > 64 * 1024 && lds > configured[wide][dev]) {
-        if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured[wide][dev] = lds;
-    }
+    if (lds > 64 * 1024)
+        configure_once(configured[wide], [&] {                 // (once, for the largest LDS the kernel can be launched with)
+            if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
     if (wide) hipLaunchKernelGGL((attention_mfma_kernel<D, 512>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
     else hipLaunchKernelGGL((attention_mfma_kernel<D, 256>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }

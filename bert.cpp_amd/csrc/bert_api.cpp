@@ -35,8 +35,13 @@ struct bert_ctx {
     HParams hp;
     Tokenizer tok;
     // one engine (weight replica + stream + workspace) per GPU; empty for tokenizer-only contexts.  Devices:
-    // BERT_HIP_DEVICES ("all" or a comma-separated list), else BERT_HIP_DEVICE (one ordinal), else every visible device
+    // BERT_HIP_DEVICES ("all" or a comma-separated list without repeats), else BERT_HIP_DEVICE (one ordinal), else the
+    // calling thread's CURRENT device — one context = one GPU unless the caller asks for more, like the reference's one
+    // context = one compute arena (eight torch.distributed ranks that each load a model must not build 64 replicas)
     std::vector<std::unique_ptr<Engine>> engines;
+    // host threads of the devices beyond the first, created once at load (multi_device.h)
+    std::unique_ptr<ShardWorkers> workers;
+    bool inject_bad_alloc = false;   // BERT_HIP_INJECT_BAD_ALLOC=1 at load time: test knob for the ABI's catch-all
     Engine *engine() const { return engines.empty() ? nullptr : engines[0].get(); }
     // device-resident results of bert_hip_eval_packed_gather: shard buffers and the gathered matrix, per device
     std::vector<std::unique_ptr<DevBuf>> shard_out, gathered;
@@ -97,10 +102,17 @@ bool context_devices(std::vector<int> &devs, std::string &err) {
         const int d = atoi(one);
         if (d < 0 || d >= ndev) { err = "BERT_HIP_DEVICE out of range"; return false; }
         devs.push_back(d);
-    } else {
+    } else if (list && strcmp(list, "all") == 0) {
         for (int d = 0; d < ndev; ++d) devs.push_back(d);
+    } else {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess || cur < 0 || cur >= ndev) cur = 0;
+        devs.push_back(cur);
     }
     if (devs.empty()) { err = "BERT_HIP_DEVICES names no device"; return false; }
+    for (size_t i = 0; i < devs.size(); ++i)
+        for (size_t j = 0; j < i; ++j)
+            if (devs[i] == devs[j]) { err = "BERT_HIP_DEVICES lists device " + std::to_string(devs[i]) + " twice"; return false; }
     return true;
 }
 
@@ -120,6 +132,8 @@ bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
                mf.hp.n_embd, "bert_load_from_file", mf.hp.n_intermediate, "bert_load_from_file", mf.hp.n_head,
                "bert_load_from_file", mf.hp.n_layer, "bert_load_from_file", mf.hp.f16);
     }
+    if (mf.legacy_q4 && !quiet)
+        printf("%s: legacy q4 layout (f32 block scales, 20 / 24-byte blocks): re-blocked at load, scales rounded to f16\n", "bert_load_from_file");
     std::unique_ptr<bert_ctx> ctx(new bert_ctx);
     ctx->hp = mf.hp;
     ctx->tok.build(std::move(mf.vocab));
@@ -130,14 +144,39 @@ bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
             fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
             return nullptr;
         }
-        for (int d : devs) {
-            Engine *e = Engine::create(mf, d, err);
-            if (!e) {
-                fprintf(stderr, "%s: %s\n", "bert_load_from_file", err.c_str());
-                return nullptr;
+        int caller_device = 0;
+        const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
+        // the replicas are built side by side (each upload is host-bound: repacking + H2D), one thread per extra device
+        std::vector<Engine *> made(devs.size(), nullptr);
+        std::vector<std::string> errs(devs.size());
+        {
+            std::vector<std::thread> builders;
+            auto build = [&](size_t i) {
+                try { made[i] = Engine::create(mf, devs[i], errs[i]); }
+                catch (const std::exception &e) { errs[i] = e.what(); }
+                catch (...) { errs[i] = "unknown exception"; }
+            };
+            for (size_t i = 1; i < devs.size(); ++i) {
+                try { builders.emplace_back(build, i); } catch (const std::system_error &) { build(i); }
             }
-            ctx->engines.emplace_back(e);
+            build(0);
+            for (auto &th : builders) th.join();
         }
+        if (have_caller_device) (void)hipSetDevice(caller_device);   // loading leaves the caller's current device alone
+        bool ok = true;
+        for (size_t i = 0; i < devs.size(); ++i) {
+            if (made[i]) ctx->engines.emplace_back(made[i]);
+            else if (ok) { fprintf(stderr, "%s: %s\n", "bert_load_from_file", errs[i].c_str()); ok = false; }
+        }
+        if (!ok) return nullptr;                              // (the engines made so far are freed with the context)
+        if (devs.size() > 1) {
+            ctx->workers.reset(new ShardWorkers((int)devs.size() - 1));
+            // the communicator of the embedding gather is made now, not inside the first timed call
+            if (!ctx->rccl.init(devs, err) && !quiet)
+                fprintf(stderr, "%s: RCCL is not available (%s): bert_hip_eval_packed_gather will fail, everything else works\n", "bert_load_from_file", err.c_str());
+            if (have_caller_device) (void)hipSetDevice(caller_device);
+        }
+        if (const char *inj = getenv("BERT_HIP_INJECT_BAD_ALLOC")) ctx->inject_bad_alloc = *inj == '1';
         if (!quiet)
             printf("%s: model size = %8.2f MB / num tensors = %zu (HBM-resident on %zu HIP device%s, first %d)\n", "bert_load_from_file",
                    mf.total_tensor_bytes / 1024.0 / 1024.0, mf.tensors.size(), devs.size(), devs.size() == 1 ? "" : "s", devs[0]);
@@ -178,12 +217,20 @@ int eval_packed_all_devices(bert_ctx *ctx, const int32_t *tokens, const int32_t 
     shard_bounds(cu, B, n_dev, bounds);
     if (bounds_out) *bounds_out = bounds;
     std::vector<std::string> errs((size_t)n_dev);
-    const int rc = dispatch_shards(bounds, [&](int r, int b0, int b1) {
+    auto eval = [&](int r, int b0, int b1) {
         // eval_packed_host takes the global token array and a window of the prefix sums
         return ctx->engines[r]->eval_packed_host(tokens, cu + b0, b1 - b0, embeddings ? embeddings + (size_t)b0 * H : nullptr, errs[r],
                                                  d_dst ? d_dst[r] : nullptr);
-    });
-    if (rc != 0)
+    };
+    int rc;
+    if (n_dev == 1 || !ctx->workers) {
+        rc = 0;
+        for (int r = 0; r < n_dev && rc == 0; ++r)
+            if (bounds[r + 1] > bounds[r]) rc = eval(r, bounds[r], bounds[r + 1]);
+    } else {
+        rc = ctx->workers->run(bounds, eval, &err);           // (a worker's exception arrives here as rc -9 + message)
+    }
+    if (rc != 0 && err.empty())
         for (auto &e : errs)
             if (!e.empty()) { err = e; break; }
     return rc;
@@ -243,8 +290,7 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
                                const int32_t *n_tokens, float *const *batch_embeddings) {
     if (!ctx->engine()) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
     if (n_batch_size <= 0) return 0;
-    if (const char *inj = getenv("BERT_HIP_INJECT_BAD_ALLOC"))   // test knob: the path an exhausted host takes
-        if (*inj == '1') throw std::bad_alloc();
+    if (ctx->inject_bad_alloc) throw std::bad_alloc();           // test knob (read once, at load): the path an exhausted host takes
     // The reference evaluates sentences in order and stops at the first one it cannot handle,
     // leaving later outputs untouched; keep that observable behaviour.
     int32_t B = 0;

@@ -327,11 +327,9 @@ static void launch_ffn_impl(FfnArgs &a, const GemmWeight &W1, bool proj, int M_p
     const int H = W1.K;
     const size_t lds = FF_CONST + (size_t)(a.I + 3 * H + 512 + (proj ? 3 * H : 0)) * sizeof(float);
     const int grid = M_pad / 128;
-    static bool configured[2][3][4][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[2][3][4];
     auto go = [&](auto kernel, int nt) {
-        if (first_launch_on_device(configured[proj][W1.type][nt])) {
-            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        configure_once(configured[proj][W1.type][nt], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
         TL_DUMP(grid >= 256, (proj ? (H / 128) * (H / 64) + 1 : 0) + 3 * (H / 64 + 2 * (H / 128)) + 4);
     };

@@ -373,10 +373,9 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
     const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
-    static bool configured[3][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[3];
     auto go = [&](auto kernel, int e) {
-        if (first_launch_on_device(configured[e]))
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
     switch (epilogue) {

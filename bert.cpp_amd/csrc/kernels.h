@@ -5,7 +5,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
+#include <thread>
 
 namespace bert_hip {
 
@@ -132,15 +134,29 @@ int qkv_attention2_max_windows(int n_sentences, int n_tokens);
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status,
                            float *out, hipStream_t stream);
 
-// The > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) is per device: `seen` is the launcher's per-kernel record.
+// The > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) is per device: `seen` is the launcher's per-kernel record.  The
+// devices of a context launch from threads of their own, and two contexts may share a device: the record is atomic, and
+// the first launcher on a device finishes the opt-in (`mark_configured`) before anybody else launches past it.
 constexpr int MAX_HIP_DEVICES = 64;
-inline bool first_launch_on_device(bool (&seen)[MAX_HIP_DEVICES]) {
+typedef std::atomic<int> DeviceFlags[MAX_HIP_DEVICES];        // 0 = not configured, 1 = being configured, 2 = done
+inline int current_device_slot() {
     int d = 0;
     (void)hipGetDevice(&d);
-    d &= MAX_HIP_DEVICES - 1;
-    if (seen[d]) return false;
-    seen[d] = true;
-    return true;
+    return d & (MAX_HIP_DEVICES - 1);
+}
+// true for exactly one caller per device: it runs the opt-in and then calls mark_configured(); everybody else waits for that
+inline bool first_launch_on_device(DeviceFlags &seen) {
+    std::atomic<int> &f = seen[current_device_slot()];
+    int expected = 0;
+    if (f.load(std::memory_order_acquire) == 2) return false;
+    if (f.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) return true;
+    while (f.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+    return false;
+}
+inline void mark_configured(DeviceFlags &seen) { seen[current_device_slot()].store(2, std::memory_order_release); }
+template <class F>
+inline void configure_once(DeviceFlags &seen, F &&opt_in) {
+    if (first_launch_on_device(seen)) { opt_in(); mark_configured(seen); }
 }
 
 // f16 [rows][cols] -> f32 (hidden-state tap)

@@ -820,10 +820,9 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
     a.I = W1.N;
     const int H = W1.K;
     const size_t lds = layer_tail_lds(H, a.I);
-    static bool configured[4][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[4];
     auto go = [&](auto kernel, int nt) {
-        if (first_launch_on_device(configured[nt]))
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configure_once(configured[nt], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
 #ifdef BERT_HIP_TIMELINE
         static int shots = 0;

@@ -2,6 +2,7 @@
 #include "model_file.h"
 
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 
 namespace bert_hip {
@@ -184,6 +185,12 @@ bool ModelFile::load(const char *fname, bool vocab_only, std::string &err) {
                     float v;
                     memcpy(&v, src + 4 * k, 4);
                     const _Float16 h = (_Float16)v;
+                    // (a finite scale outside f16's range would silently become inf or 0: refuse the file instead)
+                    const float back = (float)h;
+                    if (std::isfinite(v) && (!std::isfinite(back) || (v != 0.f && back == 0.f))) {
+                        err = "tensor '" + name + "': a legacy q4 block scale (" + std::to_string(v) + ") does not fit f16";
+                        return false;
+                    }
                     memcpy(out + 2 * k, &h, 2);
                 }
                 uint8_t el[32];

@@ -3,7 +3,12 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 namespace bert_hip {
@@ -30,16 +35,110 @@ void shard_bounds(const int32_t *cu, int n, int n_shards, std::vector<int> &boun
     }
 }
 
-int dispatch_shards(const std::vector<int> &bounds, const std::function<int(int, int, int)> &eval) {
-    const int n_shards = (int)bounds.size() - 1;
-    std::vector<int> rc((size_t)n_shards, 0);
-    std::vector<std::thread> pool;
-    for (int r = 1; r < n_shards; ++r)
-        if (bounds[r + 1] > bounds[r]) pool.emplace_back([&, r] { rc[r] = eval(r, bounds[r], bounds[r + 1]); });
-    if (n_shards > 0 && bounds[1] > bounds[0]) rc[0] = eval(0, bounds[0], bounds[1]);
-    for (auto &t : pool) t.join();
+// ---- persistent shard workers
+namespace {
+std::atomic<long> g_threads_created{0};
+
+// guards one call of eval: no exception crosses a thread boundary (or, on the caller's thread, the C ABI one level up)
+int guarded_eval(const std::function<int(int, int, int)> &eval, int r, int b0, int b1, std::string &msg) {
+    try {
+        return eval(r, b0, b1);
+    } catch (const std::exception &e) {
+        msg = e.what();
+    } catch (...) {
+        msg = "unknown exception";
+    }
+    return -9;
+}
+}  // namespace
+
+struct ShardWorkers::Impl {
+    struct Slot {
+        std::thread th;
+        std::mutex m;
+        std::condition_variable cv;
+        const std::function<int(int, int, int)> *job = nullptr;     // non-null: work to do
+        int r = 0, b0 = 0, b1 = 0, rc = 0;
+        bool done = false, quit = false;
+        std::string msg;
+    };
+    std::vector<std::unique_ptr<Slot>> slots;
+
+    static void loop(Slot *s) {
+        std::unique_lock<std::mutex> lk(s->m);
+        for (;;) {
+            s->cv.wait(lk, [&] { return s->job || s->quit; });
+            if (s->quit) return;
+            const auto *job = s->job;
+            lk.unlock();
+            std::string msg;
+            const int rc = guarded_eval(*job, s->r, s->b0, s->b1, msg);
+            lk.lock();
+            s->rc = rc;
+            s->msg = std::move(msg);
+            s->job = nullptr;
+            s->done = true;
+            s->cv.notify_all();
+        }
+    }
+};
+
+ShardWorkers::ShardWorkers(int n_workers) : impl_(nullptr) {
+    try {
+        impl_ = new Impl;
+        for (int k = 0; k < n_workers; ++k) {
+            std::unique_ptr<Impl::Slot> s(new Impl::Slot);
+            s->th = std::thread(Impl::loop, s.get());         // std::system_error: stop here, the rest run on the caller
+            g_threads_created.fetch_add(1);
+            impl_->slots.push_back(std::move(s));
+            threads_.push_back(nullptr);
+        }
+    } catch (...) {
+    }
+}
+
+ShardWorkers::~ShardWorkers() {
+    if (!impl_) return;
+    for (auto &s : impl_->slots) {
+        { std::lock_guard<std::mutex> lk(s->m); s->quit = true; }
+        s->cv.notify_all();
+        if (s->th.joinable()) s->th.join();
+    }
+    delete impl_;
+}
+
+long ShardWorkers::threads_created() { return g_threads_created.load(); }
+
+int ShardWorkers::run(const std::vector<int> &bounds, const std::function<int(int, int, int)> &eval, std::string *err) {
+    const int n_shards = (int)bounds.size() - 1, n_workers = impl_ ? (int)impl_->slots.size() : 0;
+    std::vector<int> rc((size_t)(n_shards > 0 ? n_shards : 0), 0);
+    std::vector<std::string> msgs(rc.size());
+    // hand shard r to worker r - 1 ...
+    for (int r = 1; r < n_shards && r - 1 < n_workers; ++r) {
+        if (bounds[r + 1] <= bounds[r]) continue;
+        Impl::Slot &s = *impl_->slots[r - 1];
+        std::lock_guard<std::mutex> lk(s.m);
+        s.r = r; s.b0 = bounds[r]; s.b1 = bounds[r + 1]; s.done = false; s.rc = 0; s.msg.clear();
+        s.job = &eval;
+        s.cv.notify_all();
+    }
+    // ... shard 0 and every shard without a worker run here ...
     for (int r = 0; r < n_shards; ++r)
-        if (rc[r]) return rc[r];
+        if ((r == 0 || r - 1 >= n_workers) && bounds[r + 1] > bounds[r]) rc[r] = guarded_eval(eval, r, bounds[r], bounds[r + 1], msgs[r]);
+    // ... and every worker is waited for before anything is returned (or rethrown): its job refers to the caller's frame
+    for (int r = 1; r < n_shards && r - 1 < n_workers; ++r) {
+        if (bounds[r + 1] <= bounds[r]) continue;
+        Impl::Slot &s = *impl_->slots[r - 1];
+        std::unique_lock<std::mutex> lk(s.m);
+        s.cv.wait(lk, [&] { return s.done; });
+        rc[r] = s.rc;
+        msgs[r] = s.msg;
+    }
+    for (int r = 0; r < n_shards; ++r)
+        if (rc[r]) {
+            if (err && !msgs[r].empty()) *err = msgs[r];
+            return rc[r];
+        }
     return 0;
 }
 
@@ -62,6 +161,15 @@ RcclGather::~RcclGather() {
 
 bool RcclGather::init(const std::vector<int> &devices, std::string &err) {
     if (ready()) return true;
+    for (size_t i = 0; i < devices.size(); ++i)
+        for (size_t j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) { err = "RCCL communicator: device " + std::to_string(devices[i]) + " is listed twice"; return false; }
+    auto fail = [&]() {                                       // nothing half-initialised stays behind (a later call starts over)
+        comms_.clear();
+        if (lib_) { dlclose(lib_); lib_ = nullptr; }
+        for (auto &f : fn_) f = nullptr;
+        return false;
+    };
     for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
         lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         if (lib_) break;
@@ -70,15 +178,14 @@ bool RcclGather::init(const std::vector<int> &devices, std::string &err) {
     const char *names[] = {"ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclBroadcast", "ncclGetErrorString"};
     for (int i = 0; i < 6; ++i) {
         fn_[i] = dlsym(lib_, names[i]);
-        if (!fn_[i]) { err = std::string("librccl.so lacks ") + names[i]; return false; }
+        if (!fn_[i]) { err = std::string("librccl.so lacks ") + names[i]; return fail(); }
     }
     devices_ = devices;
     comms_.assign(devices.size(), nullptr);
     const int rc = ((fn_comm_init_all)fn_[F_INIT])(comms_.data(), (int)devices.size(), devices.data());
     if (rc != 0) {
         err = std::string("ncclCommInitAll: ") + ((fn_err)fn_[F_ERR])(rc);
-        comms_.clear();
-        return false;
+        return fail();
     }
     return true;
 }

@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -17,9 +18,29 @@ namespace bert_hip {
 // Shards are contiguous, in order, balanced by TOKEN count; a shard may be empty.  Same rule as bert.cpp_amd/dist.py.
 void shard_bounds(const int32_t *cu_seqlens, int n_sentences, int n_shards, std::vector<int> &bounds);
 
-// eval(shard, first, last) for every non-empty shard: shard 0 on the calling thread, the others on threads of their own.
-// Returns 0, or the first non-zero result.
-int dispatch_shards(const std::vector<int> &bounds, const std::function<int(int, int, int)> &eval);
+// The host threads of a multi-device context: worker r - 1 serves shard r (device r) for the life of the context, shard 0
+// runs on the calling thread.  Threads are created ONCE (a forward pass takes under a millisecond: creating and joining
+// threads per call is a visible fraction of an 8-GPU step); a worker that cannot be started is not an error, its shard runs on
+// the caller.  No exception leaves a worker: it becomes a non-zero result and a message.
+class ShardWorkers {
+public:
+    explicit ShardWorkers(int n_workers);
+    ~ShardWorkers();
+    ShardWorkers(const ShardWorkers &) = delete;
+    ShardWorkers &operator=(const ShardWorkers &) = delete;
+    int n_threads() const { return (int)threads_.size(); }
+    // eval(shard, first, last) for every non-empty shard.  Returns 0, or the first (lowest shard) non-zero result; *err
+    // receives the message of an exception thrown by eval (result -9).  Calls are serialised by the caller (a bert_ctx is not
+    // thread-safe, like the reference's).
+    int run(const std::vector<int> &bounds, const std::function<int(int, int, int)> &eval, std::string *err = nullptr);
+    // threads this process has created for shard work so far (test hook: a thousand calls must not create a thousand threads)
+    static long threads_created();
+
+private:
+    struct Impl;
+    Impl *impl_;
+    std::vector<void *> threads_;       // (std::thread objects live in Impl; this only counts them)
+};
 
 // RCCL (librccl.so, loaded on first use: libbert.so has no link-time dependency on it), one communicator per device.
 class RcclGather {

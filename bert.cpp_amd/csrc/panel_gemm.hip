@@ -195,11 +195,9 @@ void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, con
     const int NT = W.N / 128;
     const size_t lds = FF_RING + (size_t)(3 * W.N + 512) * sizeof(float);
     const dim3 grid(M_pad / 128), block(512);
-    static bool configured[3][4][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[3][4];
     auto go = [&](auto kernel) {
-        if (first_launch_on_device(configured[W.type][NT])) {
-            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        configure_once(configured[W.type][NT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
     };
 #define PROJ_NT(WTV)                                                     \
@@ -217,11 +215,9 @@ void launch_panel_store(const GemmWeight &W, const half_t *A, const float *bias,
     a.A = A; a.W = W.w16; a.qs = W.qs; a.sc = W.sc; a.bias = bias; a.resid = nullptr; a.gamma = nullptr; a.beta = nullptr; a.out = out;
     a.N = W.N; a.K = W.K;
     const size_t lds = FF_RING + 32768 + (size_t)W.N_pad * sizeof(float);
-    static bool configured[3][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[3];
     auto go = [&](auto kernel) {
-        if (first_launch_on_device(configured[W.type])) {
-            hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        configure_once(configured[W.type], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
     };
     if (W.type == GW_F16) go(panel_store_kernel<GW_F16>);

@@ -434,11 +434,9 @@ void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *
     a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.out = out; a.n_head = n_head;
     const int KT = Wqkv.K / 64;
     const size_t lds = (size_t)KT * 16384 + 9 * QA_WSLOT + 2 * QA_TOK * 64 + 32 * QA_VT_LD * 2;
-    static bool configured[3][7][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[3][7];
     auto go = [&](auto kernel) {
-        if (first_launch_on_device(configured[Wqkv.type][KT])) {
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        configure_once(configured[Wqkv.type][KT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(n_sentences), dim3(512), lds, stream, a);
         TL_DUMP(n_sentences >= 256, 136);
     };

@@ -157,9 +157,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     const int slot = blk * 32 + l31;
     int gtok = -1, k0 = 0, k1 = 0;                            // this lane's slot: global token, key range of its sentence
     {
+        // (uniform rule, no window list: spw = 128 / round16(max_len) sentences per window.  A sentence longer than the
+        // promised max_len is cut to round16(max_len) slots here — it is the one that gets a NaN row from the length guard —
+        // instead of pushing its window neighbours past slot 127, where their rows would never be written)
+        const int place = a.groups ? 128 : 128 / a.spw;
         int off = 0;
         for (int j = 0; j < count; ++j) {
-            const int t0 = a.cu[first + j], n = a.cu[first + j + 1] - t0;
+            const int t0 = a.cu[first + j], n = min(a.cu[first + j + 1] - t0, place);
             if (slot >= off && slot < off + n) { gtok = t0 + slot - off; k0 = off; k1 = off + n; }
             off = (off + n + 15) & ~15;
         }
@@ -549,10 +553,9 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;
     const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * Wqkv.K * sizeof(float);
-    static bool configured[8][MAX_HIP_DEVICES] = {};
+    static DeviceFlags configured[8];
     auto go = [&](auto kernel) {
-        if (first_launch_on_device(configured[KT]))
-            (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configure_once(configured[KT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
         TL_DUMP_RAW(grid >= 256, 256);
     };

@@ -5,6 +5,8 @@
 #include <vector>
 
 #include "../../include/bert_hip_test.h"
+#include <stdexcept>
+
 #include "engine.h"
 #include "multi_device.h"
 
@@ -371,11 +373,17 @@ int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_
     return n;
 }
 
+int64_t bert_hip_test_shard_threads_created(void) { return (int64_t)ShardWorkers::threads_created(); }
+
 int32_t bert_hip_test_dispatch(const bert_vocab_id *tokens, const int32_t *cu_seqlens, int32_t n_sentences, int32_t n_shards,
                                int32_t H, float *out) {
     std::vector<int> bounds;
     shard_bounds(cu_seqlens, n_sentences, n_shards, bounds);
-    return dispatch_shards(bounds, [&](int shard, int b0, int b1) {
+    // one pool for the life of the process, like a context's (sized for the largest shard count seen so far)
+    static std::unique_ptr<ShardWorkers> pool;
+    if (!pool || pool->n_threads() < n_shards - 1) pool.reset(new ShardWorkers(n_shards - 1));
+    return pool->run(bounds, [&](int shard, int b0, int b1) {
+        if (H < 0) throw std::runtime_error("injected failure in shard " + std::to_string(shard));
         // stands in for Engine::eval_packed_host(tokens, cu + b0, b1 - b0, out + b0 * H): the global token array and a
         // window of the prefix sums, results into the caller's rows of this shard
         const int32_t *cu = cu_seqlens + b0;

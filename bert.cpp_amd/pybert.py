@@ -31,7 +31,7 @@ BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
     "bert_hip_test_build_windows_device", "bert_hip_test_max_windows",
-    "bert_hip_test_dispatch", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
+    "bert_hip_test_dispatch", "bert_hip_test_shard_threads_created", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
     "bert_hip_test_model_digest",
 ]
 TEST_LIB_PATH = LIB_PATH[:-3] + "_test.so"
@@ -131,6 +131,8 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_max_windows.argtypes = [i32, i32]
     L.bert_hip_test_build_windows_device.restype = i32
     L.bert_hip_test_build_windows_device.argtypes = [i32p, i32, i32p]
+    L.bert_hip_test_shard_threads_created.restype = C.c_int64
+    L.bert_hip_test_shard_threads_created.argtypes = []
     L.bert_hip_test_dispatch.restype = i32
     L.bert_hip_test_dispatch.argtypes = [i32p, i32p, i32, i32, i32, C.POINTER(C.c_float)]
     _test_lib = L
@@ -192,14 +194,18 @@ def max_windows(n_sentences: int, n_tokens: int) -> int:
     return int(test_lib().bert_hip_test_max_windows(n_sentences, n_tokens))
 
 
-def dispatch_stub(tokens: np.ndarray, cu_seqlens: np.ndarray, n_shards: int, H: int = 4) -> np.ndarray:
+def dispatch_stub(tokens: np.ndarray, cu_seqlens: np.ndarray, n_shards: int, H: int = 4, throw: bool = False) -> np.ndarray:
     tokens = np.ascontiguousarray(tokens, dtype=np.int32)
     cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
-    out = np.full((len(cu) - 1, H), np.nan, dtype=np.float32)
-    r = test_lib().bert_hip_test_dispatch(_i32p(tokens), _i32p(cu), len(cu) - 1, n_shards, H, _f32p(out))
+    out = np.full((len(cu) - 1, abs(H)), np.nan, dtype=np.float32)
+    r = test_lib().bert_hip_test_dispatch(_i32p(tokens), _i32p(cu), len(cu) - 1, n_shards, -H if throw else H, _f32p(out))
     if r != 0:
         raise RuntimeError(f"bert_hip_test_dispatch failed: {r}")
     return out
+
+
+def shard_threads_created() -> int:
+    return int(test_lib().bert_hip_test_shard_threads_created())
 
 
 def _f32p(a: np.ndarray):

@@ -47,11 +47,11 @@ BERT_API int32_t bert_hip_encode_batch(struct bert_ctx *ctx, int32_t n_threads, 
 BERT_API int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens,
                                       const int32_t *cu_seqlens, int32_t n_sentences, float *embeddings);
 
-/* Multi-GPU contexts (BERT_HIP_DEVICES, default: every visible device): bert_eval_batch / bert_encode_batch /
+/* Multi-GPU contexts (BERT_HIP_DEVICES=all or a list; default: the calling thread's current device only): bert_eval_batch / bert_encode_batch /
  * bert_hip_eval_packed cut a call into contiguous shards with near-equal token counts, one per device (weights are
  * replicated, each device has its own host thread and stream), and every shard writes its embeddings straight into
  * the caller's host rows.  bert_hip_eval_packed_gather keeps the results on the devices instead and runs the path's one
- * exchange step — an RCCL all-gather over xGMI (librccl.so is loaded on first use) — so that afterwards EVERY device
+ * exchange step — an RCCL all-gather over xGMI (librccl.so is loaded, and the communicator made, when the model is loaded) — so that afterwards EVERY device
  * holds the whole [n_sentences][n_embd] f32 matrix: d_embeddings[d] receives the pointer on device d (owned by the
  * context, valid until the next call; bert_hip_n_devices entries).  Blocking.  Per-sentence results are the same bits
  * whatever the number of devices.  Returns 0, negative on error.                                                      */
@@ -93,7 +93,8 @@ BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
 BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
 
 /* Engine knobs (also settable through the environment before bert_load_from_file):
- *   BERT_HIP_DEVICES       "all" (default) or a comma-separated list of HIP ordinals: the GPUs of the context
+ *   BERT_HIP_DEVICES       "all" or a comma-separated list of HIP ordinals without repeats: the GPUs of the context
+ *                          (default: the calling thread's current device — one context, one GPU, unless asked otherwise)
  *   BERT_HIP_DEVICE        one ordinal (older spelling of BERT_HIP_DEVICES=<d>)
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls

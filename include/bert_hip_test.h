@@ -84,10 +84,13 @@ BERT_API int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t 
 BERT_API int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens);
 /* The same windows from the device-side builder the asynchronous device API uses (needs a GPU; -1 on a HIP error).        */
 BERT_API int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows);
-/* The multi-device dispatcher (shard, one thread per shard, results straight into the caller's rows) driven with a stub
- * evaluator instead of GPUs: row b of `out` [n_sentences][H] becomes f(sentence b) = {sum of ids, length, shard, ...}.  */
+/* The multi-device dispatcher (shards, a persistent worker thread per shard beyond the first, results straight into the
+ * caller's rows) driven with a stub evaluator instead of GPUs: row b of `out` [n_sentences][H] becomes f(sentence b) =
+ * {sum of ids, length, shard, ...}.  H < 0: the stub throws inside every shard (the exception must come back as -9).      */
 BERT_API int32_t bert_hip_test_dispatch(const bert_vocab_id *tokens, const int32_t *cu_seqlens, int32_t n_sentences,
                                         int32_t n_shards, int32_t H, float *out);
+/* Threads this process has created for shard work so far (ShardWorkers): repeated calls must not create threads.          */
+BERT_API int64_t bert_hip_test_shard_threads_created(void);
 
 #ifdef __cplusplus
 }

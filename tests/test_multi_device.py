@@ -88,6 +88,24 @@ def test_dispatcher_with_a_stub_evaluator(n_shards):
             assert out[b].tolist() == want, (n, b)
 
 
+def test_dispatcher_keeps_its_threads_and_survives_exceptions():
+    """A context's shard threads are created once: a thousand back-to-back calls create none (a forward pass takes under a
+    millisecond; thread creation per call was the first suspect for sub-linear 8-GPU scaling).  An exception inside a
+    shard — on a worker or on the caller's thread — comes back as an error code, and the pool keeps working."""
+    lens = np.full(64, 32)
+    cu = _cu(lens)
+    toks = np.arange(int(cu[-1]), dtype=np.int32)
+    want = pybert.dispatch_stub(toks, cu, 8)
+    before = pybert.shard_threads_created()
+    for _ in range(1000):
+        assert np.array_equal(pybert.dispatch_stub(toks, cu, 8), want)
+    assert pybert.shard_threads_created() == before
+    with pytest.raises(RuntimeError, match="-9"):
+        pybert.dispatch_stub(toks, cu, 8, throw=True)
+    assert np.array_equal(pybert.dispatch_stub(toks, cu, 8), want)
+    assert pybert.shard_threads_created() == before
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 class _Hip:
     """Just enough of the HIP runtime through ctypes (the runtime libbert.so itself is linked against)."""
@@ -204,17 +222,17 @@ def test_device_api_packs_short_sentences_like_the_host_api(make_model, mean_len
 @pytest.mark.gpu
 def test_no_exception_crosses_the_abi(make_model, capfd, monkeypatch):
     path, hp = make_model("tiny", "f16", 1)
-    m = pybert.BertModel(path)
     s = np.arange(5, dtype=np.int32)
-    monkeypatch.setenv("BERT_HIP_INJECT_BAD_ALLOC", "1")
+    monkeypatch.setenv("BERT_HIP_INJECT_BAD_ALLOC", "1")    # (read once, when a model is loaded)
+    m = pybert.BertModel(path)
+    monkeypatch.delenv("BERT_HIP_INJECT_BAD_ALLOC")
     out = m.eval_batch([s, s])
     assert np.isnan(out).all()                              # outputs untouched, the process is alive
     assert "bert_eval_batch: std::bad_alloc" in capfd.readouterr().err
     n, out = m.encode_batch_count(["a b", "c"])
     assert n == -1 or n == 0
     assert np.isnan(out).all()
-    monkeypatch.delenv("BERT_HIP_INJECT_BAD_ALLOC")
-    assert np.isfinite(m.eval_batch([s])).all()
+    assert np.isfinite(pybert.BertModel(path).eval_batch([s])).all()
 
 
 @pytest.mark.gpu
