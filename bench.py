@@ -187,13 +187,13 @@ def committed_traffic(cfg_key, kernel):
         return None
 
 
-def kernel_roofline(res, torch, device, steps=5):
+def kernel_roofline(res, torch, device, steps=5, sync=None):
     """Per-kernel HIP-event timing in a separate pass (events around every launch, on the launch stream)."""
     model = res["model"]
     model.profile(True)
     for _ in range(steps):
         res["step"]()
-    torch.cuda.synchronize(device)
+    (sync or (lambda: torch.cuda.synchronize(device)))()
     rep = model.profile_report()
     model.profile(False)
     if not rep:
@@ -217,10 +217,11 @@ def kernel_roofline(res, torch, device, steps=5):
 
 
 def host_api_rate(res, calls=None):
-    """Host-to-host: ids in host memory -> embeddings in host memory through bert_hip_eval_packed (blocking)."""
+    """Host-to-host: ids in host memory -> embeddings in host memory through bert_hip_eval_packed (blocking): SURVEY.md
+    §8(d)'s metric as the reference's callers see it (bert_eval_batch = this after packing its pointer arrays)."""
     m, flat, cu = res["model"], res["flat"], res["cu"]
     B = len(cu) - 1
-    calls = calls or max(3, min(50, int(0.25 / max(res["ms_per_step"] * 1e-3, 1e-4))))
+    calls = calls or max(5, min(200, int(0.5 / max(res["ms_per_step"] * 1e-3, 1e-4))))
     for _ in range(2):
         out = m.eval_packed(flat, cu)
     ts = []
@@ -231,6 +232,41 @@ def host_api_rate(res, calls=None):
     med = float(np.median(ts))
     return {"value": B / med, "unit": "sentences/s", "ms_per_call": 1e3 * med, "min": B / max(ts), "max": B / min(ts), "calls": calls,
             "entry": "bert_hip_eval_packed (host ids -> host embeddings: pinned staging, H2D, forward, D2H, blocking)"}, out
+
+
+def latency_b1(tmpdir, calls=200):
+    """One sentence per call, host to host (bert_hip_eval_packed with n_sentences = 1: what bert_encode / the reference's
+    server loop do per request, reference bert.cpp:943-950, examples/server.cpp:98-114): median microseconds of `calls`
+    calls, and the per-kernel HIP-event times of the same call."""
+    out = {}
+    for ftype in ("f16", "q4_0"):
+        path = os.path.join(tmpdir, f"minilm-l6_{ftype}_rank0.bin")
+        if not os.path.exists(path):
+            gf.make_synthetic_model(path, "minilm-l6", ftype, seed=0)
+        m = pybert.BertModel(path)
+        hp = gf.MODEL_DIMS["minilm-l6"]
+        for n in (128, 25):
+            ids = gf.synthetic_token_ids(1, n, hp.n_vocab, seed=77).reshape(-1)
+            cu = np.array([0, n], dtype=np.int32)
+            for _ in range(10):
+                m.eval_packed(ids, cu)
+            ts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                m.eval_packed(ids, cu)
+                ts.append(time.perf_counter() - t0)
+            m.profile(True)
+            for _ in range(5):
+                m.eval_packed(ids, cu)
+            rep = m.profile_report()
+            m.profile(False)
+            ts = np.asarray(ts) * 1e6
+            out[f"{ftype}_n{n}"] = {"median_us": float(np.median(ts)), "p10_us": float(np.percentile(ts, 10)), "p90_us": float(np.percentile(ts, 90)),
+                                    "calls": calls, "launches": int(sum(v["launches"] for v in rep.values()) // 5),
+                                    "kernel_us": {k: round(1e3 * v["total_ms"] / 5, 1) for k, v in sorted(rep.items())}}
+        m.close()
+    out["entry"] = "bert_hip_eval_packed, n_sentences = 1, all-MiniLM-L6-v2 dims (host ids -> host embedding, blocking)"
+    return out
 
 
 def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None):
@@ -282,7 +318,8 @@ def report(res, world, torch, device, args, prof_steps, cpu_budget):
 
 def run_inproc(args):
     """ONE process drives N GPUs through libbert.so's own multi-device layer (BERT_HIP_DEVICES): token-balanced shards, one
-    host thread + stream per device, RCCL all-gather of the embeddings (bert_hip_eval_packed_gather).  Host-resident ids."""
+    persistent host thread + stream per device, RCCL all-gather of the embeddings (bert_hip_eval_packed_gather).  Host-resident
+    ids.  The line carries the same objects as the torchrun line: regions, roofline (device 0's kernels), cpu_baseline."""
     n = args.gpus
     os.environ["BERT_HIP_DEVICES"] = ",".join(str(d) for d in range(n))
     cfg = CONFIGS[args.config]
@@ -293,11 +330,16 @@ def run_inproc(args):
         m = load_model(cfg, path)
         ids, cu, _ = config_inputs(dict(cfg, batch=cfg["batch"] * n), args.config, hp, 0)
         B = len(cu) - 1
-        regions = timed_regions(lambda: m.eval_packed_gather(ids, cu), args.steps, args.warmup, args.repeat, lambda: None)
+        step = lambda: m.eval_packed_gather(ids, cu)
+        regions = timed_regions(step, args.steps, args.warmup, args.repeat, lambda: None)
         dt = float(np.median(regions))
         r = sorted(B * args.steps / np.asarray(regions))
         fps = flops_per_sentence(hp, cfg["seq_len"] or 25)
-        print(json.dumps({
+        # per-kernel HIP-event times of device 0 (every device runs the same launches on its shard)
+        res = dict(cfg=cfg, cfg_id=args.config, hp=hp, model=m, path=path, flat=ids, cu=cu, step=step, tokens=int(cu[-1]),
+                   value=B * args.steps / dt, ms_per_step=1e3 * dt / args.steps, steps=args.steps, regions=regions)
+        roof, bd = kernel_roofline(res, None, None, steps=3, sync=lambda: None)
+        line = {
             "metric": "sentences/sec (seq_len=%s)" % cfg["seq_len"], "value": B * args.steps / dt, "unit": "sentences/s", "n_gpus": m.n_devices(),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic (seeded random weights in bert.cpp file format, random token ids)",
@@ -305,7 +347,15 @@ def run_inproc(args):
                        "weights": cfg["ftype"], "parallelism": f"dp{n} inside one process (libbert.so: one engine + thread + stream per device, "
                                                                 "RCCL all-gather of embeddings per step; ids start in HOST memory)"},
             "regions": {"n": len(r), "steps_each": args.steps, "median": float(np.median(r)), "min": float(r[0]), "max": float(r[-1])},
-            "path_mfma_frac": B * args.steps / dt * fps / (n * MFMA_PEAK_F16)}))
+            "path_gflop_per_sentence": fps / 1e9, "path_mfma_frac": B * args.steps / dt * fps / (n * MFMA_PEAK_F16),
+            "roofline": roof, "kernel_ms_per_step": bd}
+        if not args.no_cpu_baseline:
+            host = m.eval_packed(ids[:int(cu[min(B, 64)])], cu[:min(B, 64) + 1])
+            res["out"] = None
+            base, mc, mn, _ = cpu_baseline_and_cosine(dict(res, cu=cu[:min(B, 64) + 1], tokens=int(cu[min(B, 64)])), budget_s=12.0, gpu=host)
+            line.update(cpu_baseline=base, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn, speedup_vs_cpu=line["value"] / base["value"])
+        print(json.dumps(line))
+        m.close()
 
 
 def main():
@@ -360,6 +410,14 @@ def main():
                                           + (", RCCL all-gather of embeddings per step)" if world > 1 else ")")},
             }
             line.update({k: v for k, v in e.items() if k not in ("workload", "value", "unit", "ms_per_step")})
+            if "host_api" in e:
+                # SURVEY.md §8(d) quotes the metric host to host; the bench contract keeps `value` on HBM-resident inputs
+                # ("the PCIe-inclusive rate ... is never `value`"), so the host-to-host rate travels beside it, in `config` too
+                line["host_to_host"] = {"value": e["host_api"]["value"], "unit": "sentences/s", "ms_per_step": e["host_api"]["ms_per_call"],
+                                        "min": e["host_api"]["min"], "max": e["host_api"]["max"], "calls": e["host_api"]["calls"],
+                                        "entry": e["host_api"]["entry"]}
+                line["device_resident"] = {"value": res["value"], "ms_per_step": res["ms_per_step"]}
+                line["config"]["host_to_host_sentences_per_s"] = e["host_api"]["value"]
         else:
             kernel_roofline(res, torch, device)
         res["model"].close()
@@ -376,6 +434,8 @@ def main():
                 kernel_roofline(r2, torch, device, steps=2 if big else 3)
             r2["model"].close()
         if rank == 0:
+            if world == 1 and args.config == 1 and args.also is None:
+                extras["latency_b1"] = latency_b1(tmpdir)
             if extras:
                 line["also"] = extras
             print(json.dumps(line))

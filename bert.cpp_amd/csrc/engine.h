@@ -95,7 +95,7 @@ private:
     std::vector<LayerWeights *> layers_;
 
     // workspace (grow-only)
-    DevBuf x_, qkv_, ctx_, y_, ff_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_;
+    DevBuf x_, qkv_, ctx_, y_, ff_, v32_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_;
     hipStream_t stream_ = nullptr;
     // the workspace serves ONE forward pass at a time: every pass waits for the previous one's event on its own stream
     hipEvent_t busy_ = nullptr;
@@ -112,7 +112,7 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, qkv2_ = true, gemm256_ = true, tail_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

@@ -218,6 +218,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_QKV2")) e->qkv2_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_GEMM256")) e->gemm256_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
+    if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
@@ -317,13 +318,15 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
+    else if (key == "latency") latency_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
 bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
     return x_.ensure(tp * H * 2, err) && qkv_.ensure(tp * 3 * H * 2, err) && ctx_.ensure(tp * H * 2, err) &&
-           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && d_out_.ensure((size_t)n_sentences * H * 4, err) &&
+           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && v32_.ensure((size_t)128 * H * 4, err) &&
+           d_out_.ensure((size_t)n_sentences * H * 4, err) &&
            windows_.ensure((size_t)n_sentences * sizeof(int2), err);
 }
 
@@ -432,7 +435,40 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             n_windows = qkv_attention2_max_windows(B, T);
         }
     }
-    for (int il = 0; il < hp_.n_layer; ++il) {
+    // The latency route (skinny.hip): at most 128 tokens = one window of the fused kernels, which would keep one CU of 256 busy
+    // per launch.  Same bits per sentence (the route must not show in the results), seven short launches per layer.
+    const bool skinny = latency_ && tail_ && qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && T <= 128 && max_len <= 128 && (dh == 32 || dh == 64) &&
+                        skinny_layer_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w) &&
+                        qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
+    if (skinny) {
+        const int tb = (T + 31) / 32, Lz = hp_.n_layer;
+        float *v32 = v32_.as<float>();
+        for (int il = 0; il < Lz; ++il) {
+            LayerWeights &L = *layers_[il];
+            // (from the second layer on the QKV kernel LayerNorms the previous layer's output itself and writes x)
+            LayerWeights *P = il ? layers_[il - 1] : nullptr;
+            timed("skinny_qkv", 2.0 * Td * 3 * H * H, s, [&] {
+                launch_skinny_gemm(0, L.qkv.w, x, P ? v32 : nullptr, P ? P->ln_out_w.as<float>() : nullptr, P ? P->ln_out_b.as<float>() : nullptr,
+                                   x, L.qkv_b.as<float>(), nullptr, qkv, nullptr, tb, s);
+            });
+            timed("attention", att_flops, s, [&] { (void)launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s); });
+            timed("skinny_proj", 2.0 * Td * H * H, s, [&] {
+                launch_skinny_gemm(1, L.o.w, ctx, nullptr, nullptr, nullptr, nullptr, L.o_b.as<float>(), x, nullptr, v32, tb, s);
+            });
+            timed("skinny_ffn_up", 2.0 * Td * H * I, s, [&] {
+                launch_skinny_gemm(2, L.ffi.w, nullptr, v32, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), y, L.ffi_b.as<float>(), nullptr, ff, nullptr, tb, s);
+            });
+            timed("skinny_ffn_down", 2.0 * Td * H * I, s, [&] {
+                launch_skinny_gemm(3, L.ffo.w, ff, nullptr, nullptr, nullptr, nullptr, L.ffo_b.as<float>(), y, nullptr, v32, tb, s);
+            });
+            if (il + 1 == Lz || d_hidden) {
+                // (the last layer, or a hidden-state tap: somebody has to materialise x now; the next QKV kernel writes the same bits again)
+                timed("skinny_layernorm", 0.0, s, [&] { launch_skinny_layernorm(v32, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, tb, H, s); });
+            }
+            tap(il + 1);
+        }
+    }
+    for (int il = 0; !skinny && il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
         if (qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths

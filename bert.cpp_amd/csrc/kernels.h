@@ -36,6 +36,18 @@ __device__ __forceinline__ f16x2_t gelu_pk16h(f16x2_t xh) {
 }
 __device__ __forceinline__ f16x2_t gelu_pk16(float a0, float a1) { return gelu_pk16h(f16x2_t{(_Float16)a0, (_Float16)a1}); }
 
+// LayerNorm statistics (sum, sum of squares over H values) -> (1 / std, -mean / std), eps 1e-5 (ggml's).  Every product and
+// sum is spelled out: with -ffp-contract=fast the compiler picks which a * b + c it fuses by the surrounding code, and kernels
+// that must agree bit for bit (layer_tail.hip and its feature-split mirror skinny.hip) share this function instead.
+// 1 / sqrt = v_rsq_f32 + one Newton step (1 ulp).
+__device__ __forceinline__ void layernorm_scale(float s1, float s2, float inv_h, float &rstd, float &nmr) {
+    const float mean = s1 * inv_h, ex2 = s2 * inv_h;
+    const float t = fmaxf(__builtin_fmaf(-mean, mean, ex2), 0.f) + 1e-5f;
+    const float r = __builtin_amdgcn_rsqf(t);
+    rstd = r * __builtin_fmaf(-0.5f * t, r * r, 1.5f);
+    nmr = -mean * rstd;
+}
+
 constexpr int GEMM_BM = 128;   // token tile
 constexpr int GEMM_BN = 128;   // feature tile
 constexpr int GEMM_BK = 64;    // reduction tile (two 32-weight quant blocks)
@@ -84,6 +96,18 @@ bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gemm
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
+// The latency route (skinny.hip): the weight mat-muls of a layer split by output features AND token blocks over up to 192
+// one-wave workgroups, for batches of at most 128 tokens; same bits per sentence as qkv_attention2 + layer_tail.
+// mode: 0 QKV projection (-> f16), 1 out-projection (+ x + bo -> f32), 2 up-projection + GELU (-> f16, fragment order),
+// 3 down-projection (+ y + b2 -> f32).  V != nullptr (modes 0, 2): the kernel LayerNorms the f32 rows V itself (gamma, beta)
+// and writes them to ln_out; else A holds the f16 token rows.  n_token_blocks = ceil(T / 32) <= 4.
+bool skinny_layer_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
+void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const float *V, const float *gamma, const float *beta,
+                        half_t *ln_out, const float *bias, const half_t *resid, half_t *out16, float *out32, int n_token_blocks,
+                        hipStream_t stream);
+// the last layer's LayerNorm 2: f32 rows -> f16 rows
+void launch_skinny_layernorm(const float *v, const float *gamma, const float *beta, half_t *out, int n_token_blocks, int H,
+                             hipStream_t stream);
 // Row-panel kernels (panel_gemm.hip): out = LayerNorm(A W^T + bias + resid) * gamma + beta, and C = A W^T + bias.
 bool panel_gemm_supported(const GemmWeight &W, bool with_ln);
 void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, const float *gamma,

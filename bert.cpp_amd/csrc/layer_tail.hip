@@ -362,11 +362,7 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         LT_STAMP(tlU, 388);
         const f32x2 o = *(const f32x2 *)(ST + (wave ^ 4) * 64 + l31 * 2);
         s1 += o[0]; s2 += o[1];
-        const float mean = s1 * (1.0f / H);
-        const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
-        ln_rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-        ln_rstd = ln_rstd * (1.5f - 0.5f * (var + 1e-5f) * ln_rstd * ln_rstd);       // one Newton step: 1 ulp of 1 / sqrt
-        ln_nmr = -mean * ln_rstd;
+        layernorm_scale(s1, s2, 1.0f / H, ln_rstd, ln_nmr);
     }
     // own block b -> fragments y0 (registers 0..7), y1 (8..15); the eight parameter reads of a block are in flight together
     auto normalise_block = [&](auto b_tag, f16x8 &y0, f16x8 &y1) __attribute__((always_inline)) {
@@ -767,11 +763,8 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
                 for (int r = 0; r < 16; ++r) { s1 += acc2[n][r]; s2 = __builtin_fmaf(acc2[n][r], acc2[n][r], s2); }
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
-            const float mean = s1 * (1.0f / H);
-            const float var = fmaxf(s2 * (1.0f / H) - mean * mean, 0.f);
-            float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);
-            rstd = rstd * (1.5f - 0.5f * (var + 1e-5f) * rstd * rstd);
-            const float nmr = -mean * rstd;
+            float rstd, nmr;
+            layernorm_scale(s1, s2, 1.0f / H, rstd, nmr);
             // fragment (q, lane) -> position (lane + 2q) & 63 of row q: the row-major read of the store loop is conflict-free.
             // The eight parameter reads of a block are in flight together.
 #pragma unroll

@@ -102,6 +102,8 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
  *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
  *   BERT_HIP_TAIL          1 (default) | 0 — one-launch kernel for out-projection + LN + FFN + LN (layer_tail.hip, f16 weights)
+ *   BERT_HIP_LATENCY       1 (default) | 0 — batches of at most 128 tokens (one sentence per call, the reference's callers) take the
+ *                          latency route: every mat-mul of a layer split over up to 192 workgroups (skinny.hip); same bits
  *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernels (sentences of up to 128 tokens)
  *   BERT_HIP_QKV2          1 (default) | 0 — their second generation (windows of whole sentences, qkv_attention2.hip)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize                            */

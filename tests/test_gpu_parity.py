@@ -415,6 +415,12 @@ def test_pool_normalize_kernel(H):
 # end to end vs the oracle
 # ------------------------------------------------------------------------------------------------
 MIN_COS = {"f32": 1 - 1e-4, "f16": 1 - 1e-4, "q4_0": 0.99, "q4_1": 0.99}
+# On the BASELINE models' dimensions the q4 paths sit far inside the north_star's 0.99: measured 0.99993 against the oracle's
+# ggml-faithful mode (the gap is the reference's 8-bit activation blocks, which the GPU path does not have) and 1 - 2e-6 against
+# its plain mode (f32 arithmetic on the SAME dequantised weights).  Asserted at what is measured, so that an error growing
+# a hundredfold fails.
+TIGHT_COS_GGML = {"f32": 1 - 1e-4, "f16": 1 - 1e-4, "q4_0": 0.9995, "q4_1": 0.9995}
+TIGHT_COS_PLAIN = 1 - 1e-4
 LENS = [1, 2, 3, 17, 31, 32, 33, 48, 64]
 
 
@@ -487,7 +493,9 @@ def test_eval_matches_oracle_baseline_models(make_model, dims, ftype, n, lens):
            for i, L in enumerate(lens)]
     got = m.eval_batch(ids)
     coss = [cosine(g, o.eval(s, orc.MODE_GGML)) for s, g in zip(ids, got)]
-    assert min(coss) >= MIN_COS[ftype], (dims, ftype, coss)
+    assert min(coss) >= (TIGHT_COS_GGML[ftype] if min(lens) >= 8 else MIN_COS[ftype]), (dims, ftype, coss)
+    plain = [cosine(g, o.eval(s, orc.MODE_PLAIN)) for s, g in zip(ids, got)]
+    assert min(plain) >= TIGHT_COS_PLAIN, (dims, ftype, plain)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -607,6 +615,34 @@ def test_legacy_q4_files_load_and_give_the_same_embeddings(tmp_path, ftype):
     assert np.array_equal(pybert.BertModel(cur).eval_batch(sents), pybert.BertModel(leg).eval_batch(sents))
 
 
+@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
+def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype):
+    """Batches of at most 128 tokens take the latency route (skinny.hip: every mat-mul of a layer split by output features
+    over many workgroups instead of one workgroup per 128 tokens).  A sentence's embedding must not depend on what it is
+    batched with, so the route has to reproduce the fused kernels' arithmetic bit for bit: a sentence alone, a few short
+    sentences together, and the same sentences inside a large batch give identical bits."""
+    path, hp = make_model("minilm-l6", ftype, 0)
+    m = pybert.BertModel(path)
+    rng = np.random.default_rng(11)
+    lens = [128, 25, 1, 77, 33, 96, 64, 5, 127, 32, 31]
+    sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in lens]
+    m.profile(True)
+    batch = m.eval_batch(sents)                              # 619 tokens: the fused batch route
+    names_batch = set(m.profile_report())
+    alone = [m.eval_batch([s])[0] for s in sents]
+    names_alone = set(m.profile_report())
+    few = m.eval_batch([sents[1], sents[2], sents[7], sents[4], sents[10]])      # 95 tokens, five sentences
+    m.profile(False)
+    assert {"qkv_attention2", "layer_tail"} <= names_batch and not any(k.startswith("skinny") for k in names_batch), names_batch
+    assert {"skinny_qkv", "skinny_proj", "skinny_ffn_up", "skinny_ffn_down", "skinny_layernorm", "attention"} <= names_alone, names_alone
+    for i, a in enumerate(alone):
+        assert np.array_equal(a, batch[i]), (ftype, lens[i], float(np.abs(a - batch[i]).max()))
+    for k, i in enumerate([1, 2, 7, 4, 10]):
+        assert np.array_equal(few[k], batch[i]), (ftype, "few", lens[i])
+    want = orc.Oracle(path).eval(sents[3])
+    assert cosine(alone[3], want) >= TIGHT_COS_GGML[ftype]
+
+
 @pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL",
                                   "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
 def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
@@ -675,7 +711,8 @@ def test_full_size_batch_properties_bert_base(make_model):
     o = orc.Oracle(path)
     sample = [0, 3, 77, B // 3, B // 2 + 5, 400, B - 2, B - 1]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
-    assert min(coss) >= MIN_COS["q4_1"], coss
+    assert min(coss) >= TIGHT_COS_GGML["q4_1"], coss
+    assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample[:2]) >= TIGHT_COS_PLAIN
 
 
 @pytest.mark.parametrize("ftype,B", [("f16", 256), ("q4_0", 1024)])
@@ -702,4 +739,31 @@ def test_full_size_batch_properties(make_model, ftype, B):
     o = orc.Oracle(path)
     sample = [0, 3, B // 3, B - 2]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
-    assert min(coss) >= MIN_COS[ftype], coss
+    assert min(coss) >= TIGHT_COS_GGML[ftype], coss
+    assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample) >= TIGHT_COS_PLAIN
+
+
+def test_full_size_batch_properties_mpnet_dims(make_model):
+    """configs[4]'s model (BERT architecture at mpnet-base dimensions, q4_0) at one GPU's share of a step: 1024 sentences of
+    128 tokens.  Unit norm, duplicates give identical bits, the H = 768 kernel family ran, and six sentences spread over
+    the batch agree with both oracle modes."""
+    path, hp = make_model("mpnet-dims", "q4_0", 0)
+    m = pybert.BertModel(path)
+    B, N = 1024, 128
+    ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 4)
+    ids[B // 2] = ids[3]
+    ids[B - 1] = ids[3]
+    cu = (np.arange(B + 1) * N).astype(np.int32)
+    m.profile(True)
+    out = m.eval_packed(ids.reshape(-1), cu)
+    rep = m.profile_report()
+    m.profile(False)
+    assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention"} <= set(rep), sorted(rep)
+    assert np.isfinite(out).all()
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
+    assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
+    o = orc.Oracle(path)
+    sample = [0, 3, B // 3, B // 2 + 5, B - 2, B - 1]
+    coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
+    assert min(coss) >= TIGHT_COS_GGML["q4_0"], coss
+    assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample[:3]) >= TIGHT_COS_PLAIN
