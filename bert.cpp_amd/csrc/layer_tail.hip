@@ -83,10 +83,61 @@ struct TailArgs {
     const half_t *wo;                 // [H_pad][H] f16
     const half_t *w1p;                // [I_pad][H] f16, k order permuted inside groups of 16 (GemmWeight::w16p)
     const half_t *w2p;                // [H_pad][I] f16, same
+    // q4_0 / q4_1 weights (kernels.h GemmWeight: nibble plane + scale plane per matrix, tile-contiguous): the matrices stay
+    // 4-bit in HBM and L2 and are expanded into the ring slots on chip
+    const uint4 *wo_qs, *w1_qs, *w2_qs;
+    const void *wo_sc, *w1_sc, *w2_sc;
     const float *bo, *g1, *be1, *b1, *b2, *g2, *be2;
     half_t *out;                      // [T_pad][H]
     int I;
 };
+
+// ---- q4 blocks -> f16 tiles.  A thread expands one block of 32 weights (16 bytes of nibbles: byte j = element j | element
+// j + 16 << 4; f16 d, or f16 {d, m}) into four 16-byte chunks of its row: v_perm_b32 builds (1024 + q) half pairs, packed f16
+// math applies (q - 8) d or q d + m — the values the f16 image holds (engine.hip row_to_f16; tile_stream.h q4_expand_to_lds).
+// PERM: the k order inside every group of 16 is [0-3, 8-11, 4-7, 12-15] (GemmWeight::w16p), plain otherwise.
+struct RawBlock { uint4 q; unsigned sc; };
+template <int WT>
+__device__ __forceinline__ RawBlock q4_load_block(const uint4 *qs, const void *sc, size_t index) {
+    RawBlock r;
+    r.q = qs[index];
+    r.sc = WT == GW_Q4_0 ? (unsigned)((const unsigned short *)sc)[index] : ((const unsigned *)sc)[index];
+    return r;
+}
+template <int WT, bool PERM, class ChunkPtr>
+__device__ __forceinline__ void q4_expand_block(const RawBlock &r, ChunkPtr chunk_ptr) {
+    const unsigned w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+    f16x2 d2, m2;
+    if (WT == GW_Q4_0) {
+        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(r.sc & 0xffffu));
+        d2 = (f16x2){d, d};
+        m2 = (f16x2){(_Float16)0, (_Float16)0};
+    } else {
+        const f16x2 dm = __builtin_bit_cast(f16x2, r.sc);
+        d2 = (f16x2){dm[0], dm[0]};
+        m2 = (f16x2){dm[1], dm[1]};
+    }
+    const f16x2 off = WT == GW_Q4_0 ? (f16x2){(_Float16)1032.0f, (_Float16)1032.0f} : (f16x2){(_Float16)1024.0f, (_Float16)1024.0f};
+    auto four = [&](unsigned word, bool high, unsigned &o0, unsigned &o1) __attribute__((always_inline)) {
+        const unsigned n4 = (high ? (word >> 4) : word) & 0x0f0f0f0fu;
+        f16x2 v0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, n4, 0x04010400u)) - off;
+        f16x2 v1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, n4, 0x04030402u)) - off;
+        if (WT == GW_Q4_0) { v0 = v0 * d2; v1 = v1 * d2; }
+        else { v0 = v0 * d2 + m2; v1 = v1 * d2 + m2; }
+        o0 = __builtin_bit_cast(unsigned, v0);
+        o1 = __builtin_bit_cast(unsigned, v1);
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h)                               // elements 0..15 (low nibbles) / 16..31 (high nibbles)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // chunk 2 h + pr: plain = elements 8 pr .. + 8 of the half (words 2 pr, 2 pr + 1); PERM = {4 pr .., 8 + 4 pr ..} (words pr, pr + 2)
+            uint4 out;
+            four(w[PERM ? pr : 2 * pr], h, out.x, out.y);
+            four(w[PERM ? pr + 2 : 2 * pr + 1], h, out.z, out.w);
+            *(uint4 *)chunk_ptr(2 * h + pr) = out;
+        }
+}
 
 // retire all but the newest N hand-issued LDS reads; the four fragments named are the ones whose MFMAs follow
 template <int N>
@@ -149,8 +200,10 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8 &a, const f16x8 &b, const f
 
 }  // namespace
 
-template <int NT>
+template <int NT, int WT>
 __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
+    constexpr bool Q4 = WT != GW_F16;
+    constexpr int VMQ = Q4 ? 63 : 0;                          // (q4: no LDS-DMA in flight, nothing for a barrier to wait for)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, NBH = 2 * NT, NB = 4 * NT, NQ = 8 * NT, NYH = 4 * NT;
     constexpr int P = NT * NT;                                // out-projection intervals (two [128 x 64] tiles each)
@@ -237,19 +290,65 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     };
     const unsigned ldsU = lds_addr(ringU), ldsD = lds_addr(ringD);
     const unsigned offH = rows_offset(H);
-    auto dma_proj = [&](int n3, int kt, unsigned tile) __attribute__((always_inline)) { dma128(wo + (size_t)n3 * 128 * H + kt * 64, offH, H * 2, tile); };
     auto up_offset = [&]() __attribute__((always_inline)) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         return (unsigned)((t * 16 + (ln >> 4)) * H * 2 + (((ln & 15) ^ (ln >> 4)) * 16));
     };
-    auto dma_up = [&](int c, int j, unsigned offU, unsigned tile) __attribute__((always_inline)) {
+    auto dma_up_f16 = [&](int c, int j, unsigned offU, unsigned tile) __attribute__((always_inline)) {
         const char *b = (const char *)(w1p + (size_t)c * 64 * H + j * 128);
         dma_m0(tile + (unsigned)(t * 4096));
         dma_piece<0>(b, offU);
         dma_piece<1>(b + (size_t)4 * H * 2, offU ^ 64u);
         dma_piece<2>(b + (size_t)8 * H * 2, offU ^ 128u);
         dma_piece<3>(b + (size_t)12 * H * 2, offU ^ 192u);
+    };
+
+    // ---- q4 weights: what the f16 form requests by LDS-DMA during interval i (the tiles of interval i + 2), this form LOADS as
+    // raw blocks into registers during interval i and EXPANDS at the start of interval i + 1 into the same ring slot (free
+    // since the barrier before; readable behind the next one).  A wave has two raw slots (A: the [128 x 64] tiles of "its"
+    // ring — out-projection, down-projection; B: the up-projection tiles, D waves only); a thread expands one block per slot.
+    // What is pending at the start of an interval is known at compile time (the requests of the interval before).
+    [[maybe_unused]] RawBlock rawA, rawB;
+    auto role_thread = [&]() __attribute__((always_inline)) {  // 0 .. 255 inside the role (made where needed, not kept)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        return t * 64 + ln;
+    };
+    auto q4_request_rows = [&](const uint4 *qs, const void *sc, int tile_index) __attribute__((always_inline)) {
+        if constexpr (Q4) rawA = q4_load_block<WT>(qs, sc, (size_t)tile_index * 256 + role_thread());
+    };
+    auto q4_request_up = [&](int c, int j) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            // [64 rows x 128 k] of chunk c, k-tile j: rows (c & 1) * 64 .. of q-tile row c >> 1, k-tiles 2 j and 2 j + 1
+            const int tidR = role_thread(), b_hi = tidR >> 7, rem = tidR & 127;
+            const size_t idx = ((size_t)((c >> 1) * (H / 64) + 2 * j + b_hi) * 128 + (c & 1) * 64) * 2 + rem;
+            rawB = q4_load_block<WT>(a.w1_qs, a.w1_sc, idx);
+        }
+    };
+    // slot A -> [128 x 64] tile at `tile` (PERM: the k order of GemmWeight::w16p); slot B -> [64 x 128] tile
+    auto q4_expand_rows = [&](auto perm_tag, char *tile) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            const int tidR = role_thread(), row = tidR >> 1, blk = tidR & 1;
+            char *const rowp = tile + row * 128;
+            const int sw = (row >> 1) & 7;
+            q4_expand_block<WT, decltype(perm_tag)::value>(rawA, [&](int k) __attribute__((always_inline)) { return rowp + (((4 * blk + k) ^ sw) << 4); });
+        }
+    };
+    auto q4_expand_up = [&](char *tile) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            const int tidR = role_thread(), b_hi = tidR >> 7, rem = tidR & 127, r = rem >> 1, blk = rem & 1;
+            char *const rowp = tile + r * 256;
+            q4_expand_block<WT, true>(rawB, [&](int k) __attribute__((always_inline)) { return rowp + (((4 * (2 * b_hi + blk) + k) ^ (r & 15)) << 4); });
+        }
+    };
+    auto dma_proj = [&](int n3, int kt, unsigned tile) __attribute__((always_inline)) {
+        if constexpr (Q4) q4_request_rows(a.wo_qs, a.wo_sc, n3 * (H / 64) + kt);
+        else dma128(wo + (size_t)n3 * 128 * H + kt * 64, offH, H * 2, tile);
+    };
+    auto dma_up = [&](int c, int j, unsigned offU, unsigned tile) __attribute__((always_inline)) {
+        if constexpr (Q4) q4_request_up(c, j);
+        else dma_up_f16(c, j, offU, tile);
     };
 
     // ---- fragment addresses: k-step kk of a tile = the address of k-step 0 with kk XORed into bits 5.. (the slot offsets are
@@ -265,6 +364,8 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     auto pre_close = [&]() __attribute__((always_inline)) { LT_STAMP_FINE(tlU, 128 + tl); LT_STAMP_FINE(tlD, 256 + tl); };
     auto next_slot = [&]() __attribute__((always_inline)) { slot = slot == 2 ? 0 : slot + 1; LT_STAMP(tlU, tl); ++tl; };
     auto slot_plus2 = [&]() __attribute__((always_inline)) { return slot == 0 ? 2 : slot - 1; };
+    [[maybe_unused]] auto slot_plus1 = [&]() __attribute__((always_inline)) { return slot == 2 ? 0 : slot + 1; };
+    using PLAIN = std::false_type; using PERMUTED = std::true_type;
 
     // ================================ out-projection ================================
     // interval p: tiles (n3, kt = 2 q) in ringU[slot] and (n3, 2 q + 1) in ringD[slot], n3 = p / NT, q = p % NT; a wave
@@ -275,6 +376,7 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         else dma_proj(n3, 2 * q + 1, ldsD + s * LT_TILE);
     };
     proj_request(0, 0);
+    q4_expand_rows(PLAIN{}, role ? ringD : ringU);            // (q4: interval 0 expanded here, interval 1 at the start of interval 0)
     proj_request(1, 1);
     LT_STAMP(tlU, 384);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");     // parameters, x, ctx fragments, intervals 0 and 1
@@ -306,18 +408,33 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
             accp[n3 * 2 + 0] = mfma16(F[2], bf[ks + 1], accp[n3 * 2 + 0]);
             accp[n3 * 2 + 1] = mfma16(F[3], bf[ks + 1], accp[n3 * 2 + 1]);
         };
-        if constexpr (LT_ABLATE & 64) {
+        // q4: the blocks requested one interval ago are expanded (into the slot of interval p + 1) in the MIDDLE of this
+        // interval and the next request follows at once: a request has a whole interval to land, and the expansion's
+        // VALU work sits between this wave's MFMA groups, under the partner wave's MFMAs.  (Four LDS stores join the queue
+        // of hand-issued reads: the wait behind them counts them.)
+        auto q4_turn = [&]() __attribute__((always_inline)) {
+            if constexpr (p + 1 < P) q4_expand_rows(PLAIN{}, (role ? ringD : ringU) + slot_plus1() * LT_TILE);
+            else if (role == 1) q4_expand_up(ringU + slot_plus1() * LT_TILE);
             const int s2 = slot_plus2();
             if constexpr (p2 < P) proj_request(p2, s2);
             else if (role == 1) dma_up(0, p2 - P, up_offset(), ldsU + s2 * LT_TILE);
+        };
+        constexpr int QW = Q4 && p + 1 < P ? 4 : 0;           // (the two intervals in which only D expands: the strict count for both roles)
+        if constexpr (LT_ABLATE & 64) {
+            if constexpr (Q4) q4_turn();
+            else {
+                const int s2 = slot_plus2();
+                if constexpr (p2 < P) proj_request(p2, s2);
+                else if (role == 1) dma_up(0, p2 - P, up_offset(), ldsU + s2 * LT_TILE);
+            }
             pre_close();
-            if (p2 < P || role == 1) close_interval<4>(); else close_interval<0>();
+            if (p2 < P || role == 1) close_interval<Q4 ? 63 : 4>(); else close_interval<VMQ>();
             next_slot();
             return;
         }
         rd(bA, 0, Fa);
         rd(bA, 1, Fb);
-        {   // requests for interval p + 2 (out-projection, or U's first two up-projection tiles)
+        if constexpr (!Q4) {   // requests for interval p + 2 (out-projection, or U's first two up-projection tiles)
             const int s2 = slot_plus2();
             if constexpr (p2 < P) proj_request(p2, s2);
             else if (role == 1) dma_up(0, p2 - P, up_offset(), ldsU + s2 * LT_TILE);
@@ -330,17 +447,19 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         mm(Fb, 8 * q + 2);
         __builtin_amdgcn_sched_barrier(0);
         rd(bB, 1, Fb);
-        wait_frags<4>(Fa);
+        if constexpr (Q4) { q4_turn(); __builtin_amdgcn_sched_barrier(0); }
+        wait_frags<4 + QW>(Fa);
         mm(Fa, 8 * q + 4);
         __builtin_amdgcn_sched_barrier(0);
         wait_frags<0>(Fb);
         mm(Fb, 8 * q + 6);
         __builtin_amdgcn_sched_barrier(0);
         pre_close();
-        if (p2 < P || role == 1) close_interval<4>(); else close_interval<0>();
+        if (p2 < P || role == 1) close_interval<Q4 ? 63 : 4>(); else close_interval<VMQ>();
         next_slot();
     });
 
+    if (role == 1) q4_expand_up(ringU + slot_plus1() * LT_TILE);           // (q4: the second up-projection tile)
     LT_STAMP(tlU, 386); LT_STAMP(tlD, 396);
     // ================================ LayerNorm 1 ================================
     // own half of the features summed here, the partner's through ST; then each role normalises its half into f16 fragments:
@@ -575,7 +694,7 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
             }
             static_assert(MAXF <= 2, "two GELU batches per interval at most");
             pre_close();
-            if constexpr (MMA) close_interval<0>(Fc); else close_interval<0>();
+            if constexpr (MMA) close_interval<VMQ>(Fc); else close_interval<VMQ>();
             next_slot();
         };
         using TT = std::true_type; using FF = std::false_type;
@@ -609,7 +728,7 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
 #pragma unroll
                     for (int m = 0; m < NYH; ++m) *(f16x8 *)(xu + m * 1024) = Y[8 * (m >> 2) + (m & 3)];
                 }
-                pre_close(); close_interval<0>(); next_slot();
+                pre_close(); close_interval<VMQ>(); next_slot();
             }
         });
         static_assert(LAGT > NG, "U needs an idle interval to hand its half of y over");
@@ -657,7 +776,10 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         // (re-read per tile: holding the chunk's four fragments would cost 12 registers more than the 256 there are)
         const unsigned aD = aR + 3 * LT_TILE;                 // ringD
         const unsigned offI = rows_offset(I);
-        auto dma_down = [&](int c, int n3, unsigned tile) __attribute__((always_inline)) { dma128(w2p + (size_t)n3 * 128 * I + c * 64, offI, I * 2, tile); };
+        auto dma_down = [&](int c, int n3, unsigned tile) __attribute__((always_inline)) {
+            if constexpr (Q4) q4_request_rows(a.w2_qs, a.w2_sc, n3 * (I / 64) + c);
+            else dma128(w2p + (size_t)n3 * 128 * I + c * 64, offI, I * 2, tile);
+        };
         const unsigned aG = lds_addr(G) + (unsigned)(t * 8192 + lane * 16);
         // D requests EVERY feed-forward tile (U's stream is the longer one: GELU, bias reads): in feed-forward interval i the
         // up-projection tile i + 2 (into ringU) and the down-projection tile i - LAGT + 2 (into ringD), four pieces each
@@ -674,17 +796,20 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         static_for<LAGT>([&](auto k_tag) __attribute__((always_inline)) {
             constexpr int k = decltype(k_tag)::value;
             constexpr bool dn = k >= LAGT - 2;
+            if constexpr (k >= 1) q4_expand_up(ringU + slot_plus1() * LT_TILE);
+            if constexpr (k == LAGT - 1) q4_expand_rows(PERMUTED{}, ringD + slot_plus1() * LT_TILE);
             request(TT{}, std::integral_constant<bool, dn>{}, k + 2, k - (LAGT - 2));
             // at the close the pieces of the interval before have landed: all but the newest 4 (+ 4)
             pre_close();
-            close_interval<dn ? 8 : 4>();
+            close_interval<Q4 ? 63 : (dn ? 8 : 4)>();
             next_slot();
         });
         // DOWN(c), tile d: acc2[4 d + ob] += W2(row block ob, k-step kk) x g(c)[kk].  UPQ: how many of the chunk's intervals
         // still have an up-projection tile to request (NT, or fewer near the end); LAST: c == NC - 1
-        auto d_chunk = [&](auto upq_tag, auto last_tag, int c) __attribute__((always_inline)) {
+        auto d_chunk = [&](auto upq_tag, auto last_tag, auto prev_up_tag, int c) __attribute__((always_inline)) {
             constexpr int UPQ = decltype(upq_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool PREV_UP = decltype(prev_up_tag)::value;    // the chunk before requested an up-projection tile in its last interval
             static_for<NT>([&](auto d_tag) __attribute__((always_inline)) {
                 constexpr int d = decltype(d_tag)::value;
                 constexpr bool up = d < UPQ, dn = !(LAST && d + 2 >= NT);
@@ -707,23 +832,36 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 using N5 = std::integral_constant<int, 5>; using N0 = std::integral_constant<int, 0>;
+                // q4: the blocks requested one interval ago are expanded (into the slots of the next interval) first thing, each
+                // followed at once by its next request: a request has a whole interval to land, the expansion's VALU work runs
+                // under U's MFMAs, and no fragment is live yet (the registers are all taken further down)
+                constexpr bool pend_up = Q4 && (d >= 1 ? d - 1 < UPQ : PREV_UP), pend_dn = Q4 && (d >= 1 ? !(LAST && d + 1 >= NT) : true);
+                if constexpr (Q4) {
+                    if constexpr (pend_up) q4_expand_up(ringU + slot_plus1() * LT_TILE);
+                    request(std::integral_constant<bool, up>{}, FF{}, c * NT + d + LAGT + 2, 0);
+                    if constexpr (pend_dn) q4_expand_rows(PERMUTED{}, ringD + slot_plus1() * LT_TILE);
+                    request(FF{}, std::integral_constant<bool, dn>{}, 0, c * NT + d + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 rd(std::integral_constant<int, 0>{}, Fa, ga);
                 rd(std::integral_constant<int, 1>{}, Fb, gb);
                 wait_group(N5{}, Fa, ga);
                 mm(Fa, ga);
                 rd(std::integral_constant<int, 2>{}, Fa, ga);
-                if constexpr (LT_DMA_SPLIT) request(std::integral_constant<bool, up>{}, FF{}, c * NT + d + LAGT + 2, 0);
-                else request(std::integral_constant<bool, up>{}, std::integral_constant<bool, dn>{}, c * NT + d + LAGT + 2, c * NT + d + 2);
+                if constexpr (!Q4) {
+                    if constexpr (LT_DMA_SPLIT) request(std::integral_constant<bool, up>{}, FF{}, c * NT + d + LAGT + 2, 0);
+                    else request(std::integral_constant<bool, up>{}, std::integral_constant<bool, dn>{}, c * NT + d + LAGT + 2, c * NT + d + 2);
+                }
                 wait_group(N5{}, Fb, gb);
                 mm(Fb, gb);
                 rd(std::integral_constant<int, 3>{}, Fb, gb);
-                if constexpr (LT_DMA_SPLIT) request(FF{}, std::integral_constant<bool, dn>{}, 0, c * NT + d + 2);
+                if constexpr (!Q4 && LT_DMA_SPLIT) request(FF{}, std::integral_constant<bool, dn>{}, 0, c * NT + d + 2);
                 wait_group(N5{}, Fa, ga);
                 mm(Fa, ga);
                 wait_group(N0{}, Fb, gb);
                 mm(Fb, gb);
                 pre_close();
-                close_interval<(up ? 4 : 0) + (dn ? 4 : 0)>();
+                close_interval<Q4 ? 63 : (up ? 4 : 0) + (dn ? 4 : 0)>();
                 next_slot();
             });
         };
@@ -731,10 +869,10 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         // chunk NC - 3 (LAGT = 2 NT), none later
         static_assert(LAGT == 2 * NT, "the request schedule below assumes D runs two chunks behind");
         (void)NUP;
-        for (int c = 0; c + 3 < NC; ++c) d_chunk(std::integral_constant<int, NT>{}, FF{}, c);
-        d_chunk(std::integral_constant<int, NT - 2>{}, FF{}, NC - 3);
-        d_chunk(std::integral_constant<int, 0>{}, FF{}, NC - 2);
-        d_chunk(std::integral_constant<int, 0>{}, TT{}, NC - 1);
+        for (int c = 0; c + 3 < NC; ++c) d_chunk(std::integral_constant<int, NT>{}, FF{}, TT{}, c);
+        d_chunk(std::integral_constant<int, NT - 2>{}, FF{}, TT{}, NC - 3);
+        d_chunk(std::integral_constant<int, 0>{}, FF{}, FF{}, NC - 2);
+        d_chunk(std::integral_constant<int, 0>{}, TT{}, FF{}, NC - 1);
 
         // ================================ LayerNorm 2 (wave-local) -> rows staged in LDS ================================
         {
@@ -798,7 +936,8 @@ static size_t layer_tail_lds(int H, int I) {
 
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2) {
     const int H = W1.K, I = W1.N;
-    if (Wo.type != GW_F16 || W1.type != GW_F16 || W2.type != GW_F16 || !W1.w16p || !W2.w16p) return false;
+    if (Wo.type != W1.type || W1.type != W2.type) return false;
+    if (W1.type == GW_F16 ? (!Wo.w16 || !W1.w16p || !W2.w16p) : (!Wo.qs || !W1.qs || !W2.qs)) return false;
     if (Wo.N != H || Wo.K != H || W2.N != H || W2.K != I) return false;
     if (H % 128 != 0 || H < 256 || H > 384 || I % 128 != 0 || I < 256) return false;     // an even number >= 4 of 64-feature chunks
     return layer_tail_lds(H, I) <= 160 * 1024;
@@ -809,13 +948,14 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
                         const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream) {
     TailArgs a;
     a.ctx = ctx; a.x = x; a.wo = Wo.w16; a.w1p = W1.w16p; a.w2p = W2.w16p;
+    a.wo_qs = Wo.qs; a.w1_qs = W1.qs; a.w2_qs = W2.qs; a.wo_sc = Wo.sc; a.w1_sc = W1.sc; a.w2_sc = W2.sc;
     a.bo = bo; a.g1 = g1; a.be1 = be1; a.b1 = b1; a.b2 = b2; a.g2 = g2; a.be2 = be2; a.out = out;
     a.I = W1.N;
     const int H = W1.K;
     const size_t lds = layer_tail_lds(H, a.I);
-    static DeviceFlags configured[4];
-    auto go = [&](auto kernel, int nt) {
-        configure_once(configured[nt], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    static DeviceFlags configured[6];
+    auto go = [&](auto kernel, int which) {
+        configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
 #ifdef BERT_HIP_TIMELINE
         static int shots = 0;
@@ -842,7 +982,12 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
         }
 #endif
     };
-    if (H == 256) go(layer_tail_kernel<2>, 2); else go(layer_tail_kernel<3>, 3);
+    const int nt3 = H == 384;
+    switch (W1.type) {
+    case GW_F16:  if (nt3) go(layer_tail_kernel<3, GW_F16>, 1); else go(layer_tail_kernel<2, GW_F16>, 0); break;
+    case GW_Q4_0: if (nt3) go(layer_tail_kernel<3, GW_Q4_0>, 3); else go(layer_tail_kernel<2, GW_Q4_0>, 2); break;
+    default:      if (nt3) go(layer_tail_kernel<3, GW_Q4_1>, 5); else go(layer_tail_kernel<2, GW_Q4_1>, 4); break;
+    }
 }
 
 }  // namespace bert_hip

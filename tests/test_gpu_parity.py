@@ -185,6 +185,47 @@ def test_layer_tail_kernel(impl, M, H, I):
     assert np.abs(got - base).max() < 2.5e-2
 
 
+def _q4_image_f16(q, wtype, shape):
+    """The f16 image of q4 blocks as the device builds it: (q - 8) d, or q d + m with ONE rounding (an f16 fma)."""
+    bs = 18 if wtype == 2 else 20
+    flat = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, bs)
+    d = flat[:, 0:2].copy().view(np.float16).astype(np.float64)
+    qs = flat[:, bs - 16:]
+    el = np.concatenate([qs & 0x0F, qs >> 4], axis=1).astype(np.float64)
+    if wtype == 2:
+        vals = (el - 8.0) * d
+    else:
+        vals = el * d + flat[:, 2:4].copy().view(np.float16).astype(np.float64)
+    return vals.astype(np.float16).reshape(shape)
+
+
+@pytest.mark.parametrize("wtype", [2, 3], ids=["q4_0", "q4_1"])
+@pytest.mark.parametrize("M,H,I", [(130, 384, 1536), (256, 256, 512), (1000, 256, 1024), (384, 384, 256), (3000, 384, 1536)])
+def test_layer_tail_kernel_q4(wtype, M, H, I):
+    """The layer tail with the weights 4-bit in HBM (BERT_HIP_Q4=fused): raw blocks fetched into registers one interval
+    ahead and expanded into the same LDS ring slots the f16 form fills by DMA — so the MFMAs see the f16 image the engine
+    builds at load by default, and the output has the bits of the f16 form run on that image."""
+    rng = np.random.default_rng(M + H + I + wtype)
+    ctx = rng.normal(0, 1, (M, H)).astype(np.float16)
+    x = rng.normal(0, 1, (M, H)).astype(np.float16)
+    quant = gf.quantize_q4_0 if wtype == 2 else gf.quantize_q4_1
+    Ws = [(rng.normal(0, 1, shp) / np.sqrt(shp[1])).astype(np.float32) for shp in ((H, H), (I, H), (H, I))]
+    if wtype == 3:
+        Ws = [w + 0.03 for w in Ws]                      # a minimum worth storing
+    qs = [quant(w) for w in Ws]
+    imgs = [_q4_image_f16(q, wtype, w.shape) for q, w in zip(qs, Ws)]
+    bo, b2 = rng.normal(0, 0.2, H), rng.normal(0, 0.2, H)
+    b1 = rng.normal(0, 0.5, I)
+    g1, g2 = 1 + rng.normal(0, 0.1, H), 1 + rng.normal(0, 0.1, H)
+    be1, be2 = rng.normal(0, 0.1, H), rng.normal(0, 0.1, H)
+    tail = (I, bo, g1, be1, b1, b2, g2, be2)
+    got = pybert.test_layer_tail(ctx, x, *[q.view(np.uint8) for q in qs], wtype, *tail, 1)
+    want = pybert.test_layer_tail(ctx, x, *[w.view(np.uint8) for w in imgs], 1, *tail, 1)
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
+    base = pybert.test_layer_tail(ctx, x, *[q.view(np.uint8) for q in qs], wtype, *tail, 0)     # five kernels, q4 GEMMs
+    assert np.abs(got.astype(np.float64) - base.astype(np.float64)).max() < 2.5e-2
+
+
 def _attention_ref(qkv, cu, n_head, d):
     T = qkv.shape[0]
     H = n_head * d
