@@ -92,53 +92,6 @@ struct TailArgs {
     int I;
 };
 
-// ---- q4 blocks -> f16 tiles.  A thread expands one block of 32 weights (16 bytes of nibbles: byte j = element j | element
-// j + 16 << 4; f16 d, or f16 {d, m}) into four 16-byte chunks of its row: v_perm_b32 builds (1024 + q) half pairs, packed f16
-// math applies (q - 8) d or q d + m — the values the f16 image holds (engine.hip row_to_f16; tile_stream.h q4_expand_to_lds).
-// PERM: the k order inside every group of 16 is [0-3, 8-11, 4-7, 12-15] (GemmWeight::w16p), plain otherwise.
-struct RawBlock { uint4 q; unsigned sc; };
-template <int WT>
-__device__ __forceinline__ RawBlock q4_load_block(const uint4 *qs, const void *sc, size_t index) {
-    RawBlock r;
-    r.q = qs[index];
-    r.sc = WT == GW_Q4_0 ? (unsigned)((const unsigned short *)sc)[index] : ((const unsigned *)sc)[index];
-    return r;
-}
-template <int WT, bool PERM, class ChunkPtr>
-__device__ __forceinline__ void q4_expand_block(const RawBlock &r, ChunkPtr chunk_ptr) {
-    const unsigned w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
-    f16x2 d2, m2;
-    if (WT == GW_Q4_0) {
-        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(r.sc & 0xffffu));
-        d2 = (f16x2){d, d};
-        m2 = (f16x2){(_Float16)0, (_Float16)0};
-    } else {
-        const f16x2 dm = __builtin_bit_cast(f16x2, r.sc);
-        d2 = (f16x2){dm[0], dm[0]};
-        m2 = (f16x2){dm[1], dm[1]};
-    }
-    const f16x2 off = WT == GW_Q4_0 ? (f16x2){(_Float16)1032.0f, (_Float16)1032.0f} : (f16x2){(_Float16)1024.0f, (_Float16)1024.0f};
-    auto four = [&](unsigned word, bool high, unsigned &o0, unsigned &o1) __attribute__((always_inline)) {
-        const unsigned n4 = (high ? (word >> 4) : word) & 0x0f0f0f0fu;
-        f16x2 v0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, n4, 0x04010400u)) - off;
-        f16x2 v1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(0x64646464u, n4, 0x04030402u)) - off;
-        if (WT == GW_Q4_0) { v0 = v0 * d2; v1 = v1 * d2; }
-        else { v0 = v0 * d2 + m2; v1 = v1 * d2 + m2; }
-        o0 = __builtin_bit_cast(unsigned, v0);
-        o1 = __builtin_bit_cast(unsigned, v1);
-    };
-#pragma unroll
-    for (int h = 0; h < 2; ++h)                               // elements 0..15 (low nibbles) / 16..31 (high nibbles)
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            // chunk 2 h + pr: plain = elements 8 pr .. + 8 of the half (words 2 pr, 2 pr + 1); PERM = {4 pr .., 8 + 4 pr ..} (words pr, pr + 2)
-            uint4 out;
-            four(w[PERM ? pr : 2 * pr], h, out.x, out.y);
-            four(w[PERM ? pr + 2 : 2 * pr + 1], h, out.z, out.w);
-            *(uint4 *)chunk_ptr(2 * h + pr) = out;
-        }
-}
-
 // retire all but the newest N hand-issued LDS reads; the four fragments named are the ones whose MFMAs follow
 template <int N>
 __device__ __forceinline__ void wait_frags(f16x8 (&f)[4]) {
@@ -329,17 +282,17 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     // slot A -> [128 x 64] tile at `tile` (PERM: the k order of GemmWeight::w16p); slot B -> [64 x 128] tile
     auto q4_expand_rows = [&](auto perm_tag, char *tile) __attribute__((always_inline)) {
         if constexpr (Q4) {
+            // chunk 4 blk + k of row `row` sits at chunk (4 blk + k) ^ ((row >> 1) & 7) = (4 blk ^ ..) ^ k
             const int tidR = role_thread(), row = tidR >> 1, blk = tidR & 1;
-            char *const rowp = tile + row * 128;
-            const int sw = (row >> 1) & 7;
-            q4_expand_block<WT, decltype(perm_tag)::value>(rawA, [&](int k) __attribute__((always_inline)) { return rowp + (((4 * blk + k) ^ sw) << 4); });
+            const int o = row * 128 + (((4 * blk) ^ ((row >> 1) & 7)) << 4);
+            q4_expand_block<WT, decltype(perm_tag)::value>(rawA, [&](int k) __attribute__((always_inline)) { return tile + (o ^ (k << 4)); });
         }
     };
     auto q4_expand_up = [&](char *tile) __attribute__((always_inline)) {
         if constexpr (Q4) {
             const int tidR = role_thread(), b_hi = tidR >> 7, rem = tidR & 127, r = rem >> 1, blk = rem & 1;
-            char *const rowp = tile + r * 256;
-            q4_expand_block<WT, true>(rawB, [&](int k) __attribute__((always_inline)) { return rowp + (((4 * (2 * b_hi + blk) + k) ^ (r & 15)) << 4); });
+            const int o = r * 256 + (((4 * (2 * b_hi + blk)) ^ (r & 15)) << 4);
+            q4_expand_block<WT, true>(rawB, [&](int k) __attribute__((always_inline)) { return tile + (o ^ (k << 4)); });
         }
     };
     auto dma_proj = [&](int n3, int kt, unsigned tile) __attribute__((always_inline)) {

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const void *word, const v
     }
 }
 
-// Same operation for f32 / f16 tables with H % 8 == 0, laid out for bandwidth: the grid is (4-token group, sentence), so
+// Same operation for f32 / f16 tables with H % 8 == 0 and q4 tables, laid out for bandwidth: the grid is (4-token group, sentence), so
 // a wave knows its sentence and position without searching cu_seqlens; a lane owns 16-byte runs of the row (8
 // features: one 16-byte load per f16 table row, one 16-byte store), NC runs per lane (H <= 512 * NC).
 typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
@@ -114,10 +114,27 @@ __device__ __forceinline__ void table_run8(const void *tab, int H, int r, int e0
         const float4 a = *(const float4 *)((const float *)tab + (size_t)r * H + e0);
         const float4 b = *(const float4 *)((const float *)tab + (size_t)r * H + e0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
+    } else if (TT == 1) {
         const f16x8m h = *(const f16x8m *)((const half_t *)tab + (size_t)r * H + e0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    } else {
+        // q4_0 / q4_1 rows as stored in the file (18 / 20-byte blocks of 32: d [, m], 16 bytes of nibbles; element j < 16 is the
+        // low nibble of byte j, element j + 16 the high one): a run of 8 is one nibble of 8 consecutive bytes.  Same
+        // arithmetic as table_elem (ggml_get_rows: (q - 8) d, q d + m in f32).
+        constexpr int bs = TT == 2 ? 18 : 20, qo = TT == 2 ? 2 : 4;
+        const unsigned char *blk = (const unsigned char *)tab + ((size_t)r * (H / 32) + (e0 >> 5)) * bs;
+        const int off = e0 & 31;
+        const float d = (float)*(const half_t *)blk;
+        const float m = TT == 3 ? (float)*(const half_t *)(blk + 2) : 0.f;
+        unsigned short q16[4];                                // (blocks are 2-byte aligned)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q16[i] = *(const unsigned short *)(blk + qo + (off & 15) + 2 * i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int byte = (q16[i >> 1] >> (8 * (i & 1))) & 0xff, q = off < 16 ? (byte & 0x0F) : (byte >> 4);
+            v[i] = TT == 2 ? (float)(q - 8) * d : (float)q * d + m;
+        }
     }
 }
 // SEARCH: the grid is (4-token group of the batch) and a wave finds its sentence by bisection of cu_seqlens on scalar loads
@@ -192,7 +209,7 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
                      const float *beta, const int32_t *tokens, const int32_t *cu_seqlens, int n_sentences, int T,
                      int H, int n_vocab, int max_len, half_t *out, hipStream_t stream) {
     if (T <= 0) return;
-    if (table_type <= 1 && H % 8 == 0 && H <= 1024 && max_len > 0) {
+    if ((table_type <= 1 ? H % 8 == 0 : H % 32 == 0) && table_type <= 3 && H <= 1024 && max_len > 0) {
         // (group, sentence) grid while at least two thirds of its workgroups have tokens, else one group per 4 tokens
         const bool search = n_sentences > 65535 || 2ll * ((max_len + 3) / 4) * n_sentences > 3ll * ((T + 3) / 4);
         const dim3 g2 = search ? dim3((T + 3) / 4) : dim3((max_len + 3) / 4, n_sentences), b2(256);
@@ -202,7 +219,9 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
             else hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC, false>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
                                     cu_seqlens, n_sentences, T, H, n_vocab, out); } while (0)
         if (table_type == 0) { if (H <= 512) EMBR(0, 1); else EMBR(0, 2); }
-        else { if (H <= 512) EMBR(1, 1); else EMBR(1, 2); }
+        else if (table_type == 1) { if (H <= 512) EMBR(1, 1); else EMBR(1, 2); }
+        else if (table_type == 2) { if (H <= 512) EMBR(2, 1); else EMBR(2, 2); }
+        else { if (H <= 512) EMBR(3, 1); else EMBR(3, 2); }
 #undef EMBR
         return;
     }

@@ -49,6 +49,8 @@ constexpr int Q2_VT_LD = Q2_WIN + 4;             // halfs per V^T row (8-byte sk
 struct Qkv2Args {
     const half_t *x;         // [T_pad][H] hidden state, packed sentences
     const half_t *w;         // [3H (padded)][H] f16: Q rows, K rows, V rows
+    const uint4 *qs;         // q4_0 / q4_1 weights instead (kernels.h GemmWeight: nibble plane + scale plane, tile-contiguous)
+    const void *sc;
     const float *bias;       // [3H]
     const int32_t *cu;       // [n_sent + 1]
     const int2 *groups;      // per workgroup {first sentence, count}; nullptr: `spw` sentences per workgroup
@@ -105,9 +107,12 @@ __device__ __forceinline__ void q2_head_barrier() {
 
 }  // namespace
 
-// H = 64 * KT = 32 * n_head; a slab = GB k-tiles, NBAR = KT / GB slabs per head
-template <int KT, int GB>
+// H = 64 * KT = 32 * n_head; a slab = GB k-tiles, NBAR = KT / GB slabs per head.  WT: GW_F16, or GW_Q4_0 / GW_Q4_1 — the
+// weights stay 4-bit in HBM and L2; the projection waves fetch the raw blocks of a slab into registers one slab period ahead
+// of expanding them into the ring slot the f16 form fills by LDS-DMA (same tile image, same MFMA sequence, same bits).
+template <int KT, int GB, int WT>
 __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
+    constexpr bool Q4 = WT != GW_F16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 64 * KT, NBAR = KT / GB, SLAB = GB * Q2_TILE, PPS = 3 * GB;   // PPS = DMA pieces per slab and wave
     static_assert(KT == 2 * GB && NBAR == 2, "");
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + loff), AS_LDS(RING + dslot * SLAB + t * Q2_TILE + rb * 4096 + wp * 1024), 16, 0, 0);
     };
     const char *const wbase = (const char *)a.w;
-    if (wave >= 4) static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, 0>{}, 0, i); });
+    if constexpr (!Q4) {
+        if (wave >= 4) static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, 0>{}, 0, i); });
+    }
 
     // ---- the window: sentences first .. first+count-1, sentence j at slots [off_j, off_j + n_j)
     int first, count;
@@ -182,7 +189,61 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             for (int ks = 0; ks < 4 * KT; ++ks) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[ks]) : "v"(xr + 16 * ks));
         }
         // (slab 0 was requested at kernel entry) slab 1 behind the x rows: the first barrier leaves it in flight
-        static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, NBAR - 1>{}, 1, i); });
+        if constexpr (!Q4) static_for<PPS>([&](auto i) __attribute__((always_inline)) { dma_piece(wbase, std::integral_constant<int, NBAR - 1>{}, 1, i); });
+
+        // ---- q4: a k-tile of a slab is [96 rows x 2 blocks of 32 weights] = three row blocks (the head's Q, K, V rows) of 64
+        // blocks: one block per lane of a wave.  Three of the four projection waves take a row block of tile t each, rotated
+        // with the tile and the slab so that the idle turn goes round: wave w takes row block rb = (w + t + slab) % 4, idle at 3.
+        // Lane l = (row r = l >> 1, k half kb = l & 1):
+        //   plane index = ((rb H/128 + h/4) H/64 + k-tile) 256 + (h % 4) 64 + l        (rows rb H + 32 h + r of Q|K|V: scalar + lane)
+        //   LDS image   = tile t, row block rb, row r: chunk c of the row at c ^ ((r >> 1) & 7), like the DMA's source swizzle
+        // The blocks of a slab are REQUESTED in the second half of the slab period before the one in whose first half they are
+        // EXPANDED (into the slot the f16 form's DMA of that period targets: two slabs ahead of the one being multiplied).
+        constexpr int NRAW = GB;
+        [[maybe_unused]] RawBlock raw[NRAW];
+        // (the lane's part of the image address is made where it is used: kept, it would be the 257th register)
+        auto q4_image_of_lane = [&]() __attribute__((always_inline)) {
+            int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(ln));
+            return (ln >> 1) * 128 + (((4 * (ln & 1)) ^ ((ln >> 2) & 7)) << 4);
+        };
+        // tile i of slab j of head hq: this wave's row block (3: none)
+        auto q4_rb = [&](int hq, int j, int i) __attribute__((always_inline)) { return (blk + i + 2 * hq + j) & 3; };
+        auto q4_request = [&](int hq, int j, int i) __attribute__((always_inline)) {
+            if constexpr (Q4) {
+                const int rb = q4_rb(hq, j, i);
+                if (rb == 3) return;
+                const int sbase = ((rb * (H / 128) + (hq >> 2)) * (H / 64) + j * GB + i) * 256 + (hq & 3) * 64;
+                raw[i] = q4_load_block<WT>(a.qs + sbase, WT == GW_Q4_0 ? (const void *)((const unsigned short *)a.sc + sbase) : (const void *)((const unsigned *)a.sc + sbase), (size_t)lane);
+            }
+        };
+        auto q4_expand = [&](int hq, int j, int dslot, int i) __attribute__((always_inline)) {
+            if constexpr (Q4) {
+                const int rb = q4_rb(hq, j, i);
+                if (rb == 3) return;
+                char *const base = RING + dslot * SLAB + i * Q2_TILE + rb * 4096;
+                const int q4_image = q4_image_of_lane();
+                q4_expand_block<WT, false>(raw[i], [&](int k) __attribute__((always_inline)) { return base + (q4_image ^ (k << 4)); });
+            }
+        };
+        if constexpr (Q4) {
+            // slabs 0 and 1 of head 0: fetched together, expanded; then the first pending request (head 1's first slab)
+            RawBlock first[2][NRAW];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NRAW; ++i) {
+                    q4_request(0, j, i);
+                    first[j][i] = raw[i];
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < NRAW; ++i) {
+                    raw[i] = first[j][i];
+                    q4_expand(0, j, j, i);
+                }
+        }
         // per-lane LDS address of the weight fragment of k-step kk of a tile: the chunk swizzle is an XOR of 2*kk + hi
         const unsigned aX0 = lds_addr(RING) + off64(l31, hi);
         unsigned aS[4];
@@ -206,9 +267,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
         // x rows and slab 0 have landed (slab 1 may still be in flight)
         [[maybe_unused]] const bool tl_sel = tid == 256;
         TL_STAMP_AT(tl_sel, 0);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(PPS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" : : "n"(Q4 ? 0 : PPS) : "memory");
 #pragma unroll
         for (int ks = 0; ks < 4 * KT; ++ks) asm volatile("" : "+v"(bf[ks]));
+        if constexpr (Q4) {
+#pragma unroll
+            for (int i = 0; i < NRAW; ++i) q4_request(min(1, n_head - 1), 0, i);
+        }
         TL_STAMP_AT(tl_sel, 1);
         read_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
@@ -219,7 +284,8 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             // V bias of this lane's feature: an untracked global load, older than every DMA piece requested during the
             // head, so the counted waits of the slab barriers cover it
             float bv;
-            asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(a.bias + 2 * H + h * 32 + l31));
+            if constexpr (Q4) bv = a.bias[2 * H + h * 32 + l31];     // (q4: no hand-counted DMA queue; the compiler's own wait)
+            else asm volatile("global_load_dword %0, %1, off" : "=v"(bv) : "v"(a.bias + 2 * H + h * 32 + l31));
             f32x4 bq[4], bk[4];
             // slab j of this head requests slab j of the next head (two slabs ahead); past the end the last head's
             // slabs are requested again, into slots nobody reads any more
@@ -235,8 +301,19 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                 constexpr int hh = decltype(hh_tag)::value, m = decltype(m_tag)::value, hs = hh % (2 * GB);
                 constexpr int i0 = (3 * hs + 1) / 2, i1 = (3 * (hs + 1) + 1) / 2;
                 const int dslot = (hh == 2 * GB - 1) ? (rslot == 2 ? 0 : rslot + 1) : (rslot == 0 ? 2 : rslot - 1);
+                if constexpr (Q4) {
+                    // half i of the slab period (i < GB): tile i of slab j of the NEXT head goes into the ring; half GB + i: tile i of the
+                    // slab after that one (slab 1 of the next head, slab 0 of the head after next) is requested.  (Nothing is expanded
+                    // in the head's last two halves, where the bias vectors and the Q / K conversions need the registers.)
+                    constexpr int j = (hh >> 1) / GB;
+                    if constexpr (m == 1) {
+                        if constexpr (hs < GB) { if (h + 1 < n_head) q4_expand(h + 1, j, dslot, hs); }
+                        else q4_request(min(j == 0 ? h + 1 : h + 2, n_head - 1), j ^ 1, hs - GB);
+                    }
+                } else {
                 if constexpr (m == 1) dma_piece(hnext, std::integral_constant<int, (hh >> 1) / GB>{}, dslot, std::integral_constant<int, i0>{});
                 if constexpr (m == 4 && i1 - i0 == 2) dma_piece(hnext, std::integral_constant<int, (hh >> 1) / GB>{}, dslot, std::integral_constant<int, i0 + 1>{});
+                }
             };
             auto mma = [&](auto par_tag, auto i_tag, auto rb_tag, auto ks_tag) __attribute__((always_inline)) {
                 constexpr int par = decltype(par_tag)::value, i = decltype(i_tag)::value, rb = decltype(rb_tag)::value, ks = decltype(ks_tag)::value;
@@ -252,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
                     // oldest first: the V bias, the second slab (complete), then the next head's first slab WITHOUT the one
                     // piece this half is about to request
                     if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h);
-                    q2_slab_barrier<PPS - 1>(F[par]);
+                    q2_slab_barrier<Q4 ? 63 : PPS - 1>(F[par]);
                     if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 1);
                     q2_take(bv);
                     rslot = rslot == 2 ? 0 : rslot + 1;
@@ -313,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
             // most: they finished head h-2 before they passed the end of head h-1).  One barrier publishes them and opens the
             // next head's first slab; in flight behind it: this wave's pieces of the next head's second slab
             if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 4);
-            q2_head_barrier<PPS>();
+            q2_head_barrier<Q4 ? 63 : PPS>();
             if (h < 8) TL_STAMP_AT(tl_sel, 2 + 6 * h + 5);
             rslot = rslot == 2 ? 0 : rslot + 1;
             set_slot();
@@ -537,7 +614,7 @@ int qkv_attention2_max_windows(int n_sentences, int n_tokens) {
 
 bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len) {
     const int H = n_head * d_head;
-    return Wqkv.type == GW_F16 && d_head == 32 && Wqkv.K == H && Wqkv.N == 3 * H && (H == 128 || H == 256 || H == 384) &&
+    return (Wqkv.type == GW_F16 ? Wqkv.w16 != nullptr : Wqkv.qs != nullptr) && d_head == 32 && Wqkv.K == H && Wqkv.N == 3 * H && (H == 128 || H == 256 || H == 384) &&
            max_len <= Q2_WIN && max_len > 0;
 }
 
@@ -547,22 +624,28 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
                            int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
                            half_t *out, hipStream_t stream) {
     Qkv2Args a;
-    a.x = x; a.w = Wqkv.w16; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.n_groups = n_groups_dev; a.out = out;
+    a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.n_groups = n_groups_dev; a.out = out;
     a.n_head = n_head; a.n_sent = n_sentences;
     a.spw = qkv_attention2_sentences_per_window(max_len);
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;
     const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * Wqkv.K * sizeof(float);
-    static DeviceFlags configured[8];
+    static DeviceFlags configured[3][8];
     auto go = [&](auto kernel) {
-        configure_once(configured[KT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        configure_once(configured[Wqkv.type][KT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
         TL_DUMP_RAW(grid >= 256, 256);
     };
-    switch (KT) {
-        case 2: go(qkv_attention2_kernel<2, 1>); break;
-        case 4: go(qkv_attention2_kernel<4, 2>); break;
-        default: go(qkv_attention2_kernel<6, 3>); break;
+    switch (KT * 4 + Wqkv.type) {
+        case 2 * 4 + GW_F16: go(qkv_attention2_kernel<2, 1, GW_F16>); break;
+        case 4 * 4 + GW_F16: go(qkv_attention2_kernel<4, 2, GW_F16>); break;
+        case 6 * 4 + GW_F16: go(qkv_attention2_kernel<6, 3, GW_F16>); break;
+        case 2 * 4 + GW_Q4_0: go(qkv_attention2_kernel<2, 1, GW_Q4_0>); break;
+        case 4 * 4 + GW_Q4_0: go(qkv_attention2_kernel<4, 2, GW_Q4_0>); break;
+        case 6 * 4 + GW_Q4_0: go(qkv_attention2_kernel<6, 3, GW_Q4_0>); break;
+        case 2 * 4 + GW_Q4_1: go(qkv_attention2_kernel<2, 1, GW_Q4_1>); break;
+        case 4 * 4 + GW_Q4_1: go(qkv_attention2_kernel<4, 2, GW_Q4_1>); break;
+        default: go(qkv_attention2_kernel<6, 3, GW_Q4_1>); break;
     }
 }
 

@@ -164,6 +164,62 @@ __device__ __forceinline__ void q4_expand_to_lds(const QRegs &r, char *tile, int
     }
 }
 
+// ---- q4 blocks -> f16 tiles.  A thread expands one block of 32 weights (16 bytes of nibbles: byte j = element j | element
+// j + 16 << 4; f16 d, or f16 {d, m}) into four 16-byte chunks of its row: v_perm_b32 builds (1024 + q) half pairs, packed f16
+// math applies (q - 8) d or q d + m — the values the f16 image holds (engine.hip row_to_f16).  Shared by layer_tail.hip and qkv_attention2.hip.
+// PERM: the k order inside every group of 16 is [0-3, 8-11, 4-7, 12-15] (GemmWeight::w16p), plain otherwise.
+struct RawBlock { uint4 q; unsigned sc; };
+template <int WT>
+__device__ __forceinline__ RawBlock q4_load_block(const uint4 *qs, const void *sc, size_t index) {
+    RawBlock r;
+    r.q = qs[index];
+    r.sc = WT == GW_Q4_0 ? (unsigned)((const unsigned short *)sc)[index] : ((const unsigned *)sc)[index];
+    return r;
+}
+template <int WT, bool PERM, class ChunkPtr>
+__device__ __forceinline__ void q4_expand_block(const RawBlock &r, ChunkPtr chunk_ptr) {
+    const unsigned w[4] = {r.q.x, r.q.y, r.q.z, r.q.w};
+    f16x2 d2, m2;
+    if (WT == GW_Q4_0) {
+        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(r.sc & 0xffffu));
+        d2 = (f16x2){d, d};
+        m2 = (f16x2){(_Float16)0, (_Float16)0};
+    } else {
+        const f16x2 dm = __builtin_bit_cast(f16x2, r.sc);
+        d2 = (f16x2){dm[0], dm[0]};
+        m2 = (f16x2){dm[1], dm[1]};
+    }
+    // The constants are made HERE, per call, behind opaque moves (gfx9 VOP3 takes no literals and one scalar operand: the
+    // byte source of v_perm_b32 has to sit in a vector register): hoisted out of the caller's loop they cost three registers for
+    // the whole kernel — or, in kernels that have none to spare, a scratch reload per use.
+    unsigned magic, sel01, sel23, offb;
+    asm volatile("v_mov_b32 %0, 0x64646464" : "=v"(magic));
+    asm volatile("s_mov_b32 %0, 0x04010400" : "=s"(sel01));
+    asm volatile("s_mov_b32 %0, 0x04030402" : "=s"(sel23));
+    if (WT == GW_Q4_0) asm volatile("s_mov_b32 %0, 0x64086408" : "=s"(offb));      // 1032, 1032
+    else asm volatile("s_mov_b32 %0, 0x64006400" : "=s"(offb));                    // 1024, 1024
+    const f16x2 off = __builtin_bit_cast(f16x2, offb);
+    auto four = [&](unsigned word, bool high, unsigned &o0, unsigned &o1) __attribute__((always_inline)) {
+        const unsigned n4 = (high ? (word >> 4) : word) & 0x0f0f0f0fu;
+        f16x2 v0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(magic, n4, sel01)) - off;
+        f16x2 v1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(magic, n4, sel23)) - off;
+        if (WT == GW_Q4_0) { v0 = v0 * d2; v1 = v1 * d2; }
+        else { v0 = v0 * d2 + m2; v1 = v1 * d2 + m2; }
+        o0 = __builtin_bit_cast(unsigned, v0);
+        o1 = __builtin_bit_cast(unsigned, v1);
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h)                               // elements 0..15 (low nibbles) / 16..31 (high nibbles)
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            // chunk 2 h + pr: plain = elements 8 pr .. + 8 of the half (words 2 pr, 2 pr + 1); PERM = {4 pr .., 8 + 4 pr ..} (words pr, pr + 2)
+            uint4 out;
+            four(w[PERM ? pr : 2 * pr], h, out.x, out.y);
+            four(w[PERM ? pr + 2 : 2 * pr + 1], h, out.z, out.w);
+            *(uint4 *)chunk_ptr(2 * h + pr) = out;
+        }
+}
+
 __device__ __forceinline__ float gelu_fast(float x) {
     const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;
     const float c2 = c1 * 0.044715f;

@@ -345,6 +345,34 @@ def test_qkv_attention2_kernel(n_head, lens, mode):
     assert len(neq) == 0, (n_head, mode, len(neq), neq[:8].tolist())
 
 
+@pytest.mark.parametrize("wtype", [2, 3], ids=["q4_0", "q4_1"])
+@pytest.mark.parametrize("mode", [2, 3], ids=["next-fit", "uniform"])
+@pytest.mark.parametrize("n_head", [4, 8, 12])
+@pytest.mark.parametrize("lens", [Q2_CASES[0] * 20, Q2_CASES[1], Q2_CASES[3], Q2_CASES[5]], ids=["full", "edges", "short", "mixed"])
+def test_qkv_attention2_kernel_q4(n_head, lens, mode, wtype):
+    """The window kernel with the Q|K|V weights 4-bit in HBM (BERT_HIP_Q4=fused): the projection waves fetch raw blocks one
+    slab period ahead and expand them into the ring slots the f16 form fills by DMA — the bits of the f16 form run on
+    the image the engine builds at load by default."""
+    d_head, H = 32, 32 * n_head
+    rng = np.random.default_rng(sum(lens) + n_head + wtype)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    x = rng.normal(0, 1, (int(cu[-1]), H)).astype(np.float16)
+    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float32)
+    W[:H] *= 1.7
+    W[:, : H // 2] *= 1.3
+    if wtype == 3:
+        W += 0.02
+    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
+    q = gf.quantize_q4_0(W) if wtype == 2 else gf.quantize_q4_1(W)
+    img = _q4_image_f16(q, wtype, W.shape)
+    got = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, mode)
+    want = pybert.test_qkv_attention(x, cu, n_head, d_head, img.view(np.uint8), 1, bias, mode)
+    neq = np.argwhere(got.view(np.uint16) != want.view(np.uint16))
+    assert len(neq) == 0, (n_head, mode, wtype, len(neq), neq[:8].tolist())
+    split = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, 0)     # q4 GEMM + attention kernel
+    assert np.abs(got.astype(np.float64) - split.astype(np.float64)).max() < 6e-3
+
+
 @pytest.mark.parametrize("n_sentences", [1, 2, 7, 511, 512, 513, 1024, 5000, 40000])
 @pytest.mark.parametrize("dist", ["short", "mixed", "full", "sixteens"])
 def test_windows_built_on_the_device_equal_the_host_builder(n_sentences, dist):
