@@ -201,9 +201,6 @@ def kernel_roofline(res, torch, device, steps=5, sync=None):
     name, st = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
     avg_s = st["total_ms"] / st["launches"] * 1e-3
     flops = st["flops_per_launch"]
-    if name.startswith("qkv_attention") and res["cfg"]["seq_len"]:
-        # the engine books attention FLOPs with an upper bound (max_len); exact for equal lengths
-        pass
     achieved = flops / avg_s if avg_s > 0 else 0.0
     total_ms = sum(v["total_ms"] for v in rep.values())
     key = res["cfg"].get("key", f"config{res['cfg_id']}")

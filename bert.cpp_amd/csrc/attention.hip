@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit; the exponent below is one
-            // fma per score (the same arithmetic as qkv_attention.hip / qkv_attention2.hip: equal bits across the kernels)
+            // fma per score (the same arithmetic as qkv_attention2.hip: equal bits across the kernels)
             const float m_new = fmaxf(m_run, mx * sc);      // finite: every chunk has >= 1 real key
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
             float psum = 0.f;

@@ -35,13 +35,15 @@ struct bert_ctx {
     HParams hp;
     Tokenizer tok;
     // one engine (weight replica + stream + workspace) per GPU; empty for tokenizer-only contexts.  Devices:
-    // BERT_HIP_DEVICES ("all" or a comma-separated list without repeats), else BERT_HIP_DEVICE (one ordinal), else the
+    // BERT_HIP_DEVICES ("all" or a comma-separated list without repeats), else the
     // calling thread's CURRENT device — one context = one GPU unless the caller asks for more, like the reference's one
     // context = one compute arena (eight torch.distributed ranks that each load a model must not build 64 replicas)
     std::vector<std::unique_ptr<Engine>> engines;
     // host threads of the devices beyond the first, created once at load (multi_device.h)
     std::unique_ptr<ShardWorkers> workers;
-    bool inject_bad_alloc = false;   // BERT_HIP_INJECT_BAD_ALLOC=1 at load time: test knob for the ABI's catch-all
+    // test knobs (bert_hip_set_option "test_inject_bad_alloc" / "test_rccl_single"): the ABI's catch-all; the exchange step
+    // through a 1-rank communicator on a single device
+    bool inject_bad_alloc = false, rccl_single = false;
     Engine *engine() const { return engines.empty() ? nullptr : engines[0].get(); }
     // device-resident results of bert_hip_eval_packed_gather: shard buffers and the gathered matrix, per device
     std::vector<std::unique_ptr<DevBuf>> shard_out, gathered;
@@ -87,7 +89,7 @@ bool context_devices(std::vector<int> &devs, std::string &err) {
         err = "no HIP device available (this library needs an AMD GPU; there is no CPU fallback)";
         return false;
     }
-    const char *list = getenv("BERT_HIP_DEVICES"), *one = getenv("BERT_HIP_DEVICE");
+    const char *list = getenv("BERT_HIP_DEVICES");
     devs.clear();
     if (list && *list && strcmp(list, "all") != 0) {
         for (const char *p = list; *p;) {
@@ -98,10 +100,6 @@ bool context_devices(std::vector<int> &devs, std::string &err) {
             devs.push_back((int)d);
             p = *end == ',' ? end + 1 : end;
         }
-    } else if ((!list || !*list) && one && *one) {
-        const int d = atoi(one);
-        if (d < 0 || d >= ndev) { err = "BERT_HIP_DEVICE out of range"; return false; }
-        devs.push_back(d);
     } else if (list && strcmp(list, "all") == 0) {
         for (int d = 0; d < ndev; ++d) devs.push_back(d);
     } else {
@@ -176,7 +174,6 @@ bert_ctx *load_impl(const char *fname, bool tokenizer_only) {
                 fprintf(stderr, "%s: RCCL is not available (%s): bert_hip_eval_packed_gather will fail, everything else works\n", "bert_load_from_file", err.c_str());
             if (have_caller_device) (void)hipSetDevice(caller_device);
         }
-        if (const char *inj = getenv("BERT_HIP_INJECT_BAD_ALLOC")) ctx->inject_bad_alloc = *inj == '1';
         if (!quiet)
             printf("%s: model size = %8.2f MB / num tensors = %zu (HBM-resident on %zu HIP device%s, first %d)\n", "bert_load_from_file",
                    mf.total_tensor_bytes / 1024.0 / 1024.0, mf.tensors.size(), devs.size(), devs.size() == 1 ? "" : "s", devs[0]);
@@ -290,7 +287,7 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
                                const int32_t *n_tokens, float *const *batch_embeddings) {
     if (!ctx->engine()) { fprintf(stderr, "bert_eval_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
     if (n_batch_size <= 0) return 0;
-    if (ctx->inject_bad_alloc) throw std::bad_alloc();           // test knob (read once, at load): the path an exhausted host takes
+    if (ctx->inject_bad_alloc) throw std::bad_alloc();           // test knob: the path an exhausted host takes
     // The reference evaluates sentences in order and stops at the first one it cannot handle,
     // leaving later outputs untouched; keep that observable behaviour.
     int32_t B = 0;
@@ -480,10 +477,9 @@ int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *t
             fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
             return -3;
         }
-        // the one exchange step of the path: every device receives every other device's shard (RCCL over xGMI).  With
-        // BERT_HIP_RCCL_SINGLE=1 a single device runs it too (a 1-rank communicator), to exercise the code on one GPU.
-        const char *force = getenv("BERT_HIP_RCCL_SINGLE");
-        if (n_dev > 1 || (force && *force == '1')) {
+        // the one exchange step of the path: every device receives every other device's shard (RCCL over xGMI).  With the
+        // option test_rccl_single a single device runs it too (a 1-rank communicator), to exercise the code on one GPU.
+        if (n_dev > 1 || ctx->rccl_single) {
             std::vector<int> devs;
             for (auto &e : ctx->engines) devs.push_back(e->device());
             if (n_dev == 1) {
@@ -583,7 +579,10 @@ int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len
 
 void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value) {
     guarded_void("bert_hip_set_option", [&] {
-        if (key && value)
+        if (!key || !value) return;
+        if (strcmp(key, "test_inject_bad_alloc") == 0) ctx->inject_bad_alloc = *value == '1';
+        else if (strcmp(key, "test_rccl_single") == 0) ctx->rccl_single = *value == '1';
+        else
             for (auto &e : ctx->engines) e->set_option(key, value);
     });
 }

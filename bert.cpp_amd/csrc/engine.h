@@ -112,7 +112,7 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, ffn_fused_ = true, panel_ = true, layer_fused_ = true, qkv_att_ = true, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

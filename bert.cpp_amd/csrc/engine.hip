@@ -209,15 +209,12 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         err = std::string("unsupported GPU architecture '") + prop.gcnArchName + "' (kernels are built for gfx950 / MI355X only)";
         delete e; return nullptr;
     }
-    if (const char *g = getenv("BERT_HIP_GEMM")) e->gemm_naive_ = strcmp(g, "naive") == 0;
-    if (const char *a = getenv("BERT_HIP_ATTN")) e->attn_naive_ = strcmp(a, "naive") == 0;
-    if (const char *f = getenv("BERT_HIP_FFN")) e->ffn_fused_ = strcmp(f, "unfused") != 0;
-    if (const char *f = getenv("BERT_HIP_PANEL")) e->panel_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_LAYER_FUSED")) e->layer_fused_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_QKV_ATT")) e->qkv_att_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_QKV2")) e->qkv2_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_GEMM256")) e->gemm256_ = strcmp(f, "0") != 0;
-    if (const char *f = getenv("BERT_HIP_TAIL")) e->tail_ = strcmp(f, "0") != 0;
+    // BERT_HIP_KERNELS = fused (default) | tiled (GEMM + attention + LayerNorm kernels, Q|K|V and the intermediate through HBM)
+    // | naive (the generic kernels: any shape, row-major f16 images); finer switches: bert_hip_set_option
+    if (const char *k = getenv("BERT_HIP_KERNELS")) {
+        if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
+        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false;
+    }
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
@@ -302,19 +299,15 @@ int Engine::check(std::string &err) {
 
 void Engine::set_option(const std::string &key, const std::string &value) {
     if (key == "gemm") {
-        // the generic kernel reads GemmWeight::naive16, an image that is only built at load time (BERT_HIP_GEMM=naive) or
+        // the generic kernel reads GemmWeight::naive16, an image that is only built at load time (BERT_HIP_KERNELS=naive) or
         // for shapes the MFMA kernels cannot take: refuse the switch when a matrix lacks it
         bool have = true;
         for (auto *L : layers_)
             for (GemmWeightStore *w : {&L->qkv, &L->o, &L->ffi, &L->ffo}) have = have && w->w.naive16 != nullptr;
         if (value == "naive" && !have)
-            fprintf(stderr, "bert_hip_set_option: gemm=naive needs BERT_HIP_GEMM=naive at load time (the f16 row-major images were not built); ignored\n");
+            fprintf(stderr, "bert_hip_set_option: gemm=naive needs BERT_HIP_KERNELS=naive at load time (the f16 row-major images were not built); ignored\n");
         else gemm_naive_ = value == "naive";
     } else if (key == "attn") attn_naive_ = value == "naive";
-    else if (key == "ffn") ffn_fused_ = value != "unfused";
-    else if (key == "panel") panel_ = value != "0";
-    else if (key == "layer_fused") layer_fused_ = value != "0";
-    else if (key == "qkv_att") qkv_att_ = value != "0";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
@@ -421,7 +414,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     // cu_seqlens when packing can pay — sentences on average clearly shorter than max_len; for full-length batches the
     // uniform rule (max_len-sized places) gives the same windows without the extra launch
     const int *d_n_windows = nullptr;
-    if (!d_windows && qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok &&
+    if (!d_windows && qkv2_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok &&
         qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len)) {
         const int spw = qkv_attention2_sentences_per_window(max_len), uniform = (B + spw - 1) / spw;
         if (4ll * uniform * 128 > 5 * ((long long)T + 8ll * B)) {
@@ -437,7 +430,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     }
     // The latency route (skinny.hip): at most 128 tokens = one window of the fused kernels, which would keep one CU of 256 busy
     // per launch.  Same bits per sentence (the route must not show in the results), seven short launches per layer.
-    const bool skinny = latency_ && tail_ && qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && T <= 128 && max_len <= 128 && (dh == 32 || dh == 64) &&
+    const bool skinny = latency_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && T <= 128 && max_len <= 128 && (dh == 32 || dh == 64) &&
                         skinny_layer_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w) &&
                         qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
     if (skinny) {
@@ -470,30 +463,18 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     }
     for (int il = 0; !skinny && il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
-        if (qkv2_ && qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
+        if (qkv2_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths
             timed("qkv_attention2", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
                 launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, d_n_windows, max_len, nh, ctx, s);
             });
-        } else
-        // one workgroup per sentence pays for 128 tokens whatever the length: worth it from ~48 tokens on average
-        if (qkv_att_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && (long long)T >= 48ll * B &&
-            qkv_attention_supported(L.qkv.w, nh, dh, max_len)) {
-            timed("qkv_attention", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
-                launch_qkv_attention(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, nh, ctx, s);
-            });
         } else {
-        if (panel_ && !gemm_naive_ && L.qkv.mfma_ok && panel_gemm_supported(L.qkv.w, false) &&
-            !(gemm256_ && H > 384 && gemm256_supported(L.qkv.w, t_pad)))
-            timed("panel_qkv", 2.0 * Td * L.qkv.w.N * L.qkv.w.K, s, [&] { launch_panel_store(L.qkv.w, x, L.qkv_b.as<float>(), qkv, t_pad, s); });
-        else
             gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
-        timed("attention", att_flops, s, [&] {
-            if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
-                launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
-        });
+            timed("attention", att_flops, s, [&] {
+                if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
+                    launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
+            });
         }
-        const bool ffn_ok = ffn_fused_ && !gemm_naive_ && L.ffi.mfma_ok && L.ffo.mfma_ok && ffn_fused_supported(L.ffi.w, L.ffo.w);
         if (tail_ && !gemm_naive_ && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && layer_tail_supported(L.o.w, L.ffi.w, L.ffo.w)) {
             // out-projection + LN + FFN + LN in one launch, a pair of specialist waves per 32 tokens: y and the intermediate
             // never leave the chip
@@ -502,32 +483,12 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                                   L.ln_att_b.as<float>(), L.ffi_b.as<float>(), L.ffo_b.as<float>(),
                                   L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
             });
-        } else if (layer_fused_ && panel_ && ffn_ok && L.o.mfma_ok && proj_ffn_fused_supported(L.o.w, L.ffi.w, L.ffo.w)) {
-            // out-projection + LN + FFN + LN of the same 128-token panels in one launch
-            timed("proj_ffn_fused", 2.0 * Td * H * H + 4.0 * Td * H * I, s, [&] {
-                launch_proj_ffn_fused(L.o.w, L.ffi.w, L.ffo.w, ctx, x, L.o_b.as<float>(), L.ln_att_w.as<float>(),
-                                      L.ln_att_b.as<float>(), y, L.ffi_b.as<float>(), L.ffo_b.as<float>(),
-                                      L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
-            });
-        } else {
-        if (panel_ && !gemm_naive_ && L.o.mfma_ok && panel_gemm_supported(L.o.w, true)) {
-            timed("proj_ln", 2.0 * Td * L.o.w.N * L.o.w.K, s, [&] {
-                launch_proj_ln(L.o.w, ctx, L.o_b.as<float>(), x, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), y, t_pad, s);
-            });
         } else {
             gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
             timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
-        }
-        if (ffn_ok) {
-            timed("ffn_fused", 4.0 * Td * H * I, s, [&] {
-                launch_ffn_fused(L.ffi.w, L.ffo.w, y, L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(),
-                                 L.ln_out_b.as<float>(), x, t_pad, s);
-            });
-        } else {
             gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
             gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
             timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
-        }
         }
         tap(il + 1);
     }

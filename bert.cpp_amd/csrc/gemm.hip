@@ -247,202 +247,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// High-occupancy variant: reduction tile 32 (one quant block), 2 x 16 KiB of LDS per workgroup, so
-// four workgroups (16 waves) share a CU and hide HBM/L2 latency by thread-level parallelism rather
-// than by a deeper software pipeline.  Epilogue math (bias, GELU, residual) happens in registers; the
-// finished f16 tile is transposed through LDS only to make every global store a full 256-B row.
-// ------------------------------------------------------------------------------------------------
-constexpr int TILE32_BYTES = 128 * 64;          // 128 rows x 32 halfs
-constexpr int STAGE32_BYTES = 2 * TILE32_BYTES;
-
-__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
-
-__device__ __forceinline__ void dma_tile32(const half_t *src, int ld, char *tile, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int g = wave * 2 + i;                   // 1 KiB = 16 rows x 64 B per wave instruction
-        const int r = g * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((r >> 2) & 3);
-        __builtin_amdgcn_global_load_lds(AS_GLOBAL(src + (size_t)r * ld + c * 8), AS_LDS(tile + g * 1024), 16, 0, 0);
-    }
-}
-
-// thread (row, half) dequantises 16 of the block's 32 weights: half 0 = low nibbles (elements 0-15),
-// half 1 = high nibbles (elements 16-31)
-template <int WT>
-__device__ __forceinline__ void dequant_half_block_to_lds(const uint4 &q, unsigned scbits, char *tile, int row, int half) {
-    const unsigned w[4] = {q.x, q.y, q.z, q.w};
-    f16x2 d2, m2;
-    if (WT == GW_Q4_0) {
-        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(scbits & 0xffffu));
-        d2 = (f16x2){d, d};
-        m2 = (f16x2){(_Float16)0, (_Float16)0};
-    } else {
-        const f16x2 dm = __builtin_bit_cast(f16x2, scbits);
-        d2 = (f16x2){dm[0], dm[0]};
-        m2 = (f16x2){dm[1], dm[1]};
-    }
-    const f16x2 off = WT == GW_Q4_0 ? (f16x2){(_Float16)1032.0f, (_Float16)1032.0f}
-                                     : (f16x2){(_Float16)1024.0f, (_Float16)1024.0f};
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        f16x2 h[4];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const unsigned word = w[jj * 2 + u];
-            const unsigned n4 = (half ? (word >> 4) : word) & 0x0f0f0f0fu;
-            nib4_to_half(n4, h[2 * u], h[2 * u + 1]);
-        }
-        unsigned o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f16x2 v = h[e] - off;
-            if (WT == GW_Q4_0) v = v * d2;
-            else v = v * d2 + m2;
-            o[e] = __builtin_bit_cast(unsigned, v);
-        }
-        uint4 out;
-        out.x = o[0]; out.y = o[1]; out.z = o[2]; out.w = o[3];
-        *(uint4 *)(tile + lds_off32(row, half * 2 + jj)) = out;
-    }
-}
-
-template <int WT, int EPI>
-__global__ __launch_bounds__(256, 4) void gemm_mfma32_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE32_BYTES];     // 32 KiB
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = lb % p.n_tiles_n, mt = lb / p.n_tiles_n;
-    const int m0 = mt * GEMM_BM, n0 = nt * GEMM_BN;
-    const int K = p.K, nk = K / 32;
-    const int wf = wave & 1, wt = wave >> 1;
-    const int l31 = lane & 31, hi = lane >> 5;
-
-    const half_t *Abase = p.A + (size_t)m0 * K;
-    const half_t *Wbase = p.w16 + (size_t)n0 * K;
-    const size_t qbase = (size_t)nt * (K / 64) * 256;    // HBM order: [kt64][row][2 blocks]
-    const int qrow = tid >> 1, qhalf = tid & 1;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    uint4 qn = {0, 0, 0, 0};
-    unsigned sn = 0;
-    auto load_q = [&](int kt) {
-        const size_t bi = qbase + (size_t)(kt >> 1) * 256 + qrow * 2 + (kt & 1);
-        qn = p.qs[bi];
-        sn = WT == GW_Q4_0 ? (unsigned)((const unsigned short *)p.sc)[bi] : ((const unsigned *)p.sc)[bi];
-    };
-
-    dma_tile32(Abase, K, smem, wave, lane);
-    if (WT == GW_F16) {
-        dma_tile32(Wbase, K, smem + TILE32_BYTES, wave, lane);
-    } else {
-        load_q(0);
-        dequant_half_block_to_lds<WT>(qn, sn, smem + TILE32_BYTES, qrow, qhalf);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        char *cur = smem + (kt & 1) * STAGE32_BYTES;
-        char *nxt = smem + ((kt + 1) & 1) * STAGE32_BYTES;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            dma_tile32(Abase + (kt + 1) * 32, K, nxt, wave, lane);
-            if (WT == GW_F16) dma_tile32(Wbase + (kt + 1) * 32, K, nxt + TILE32_BYTES, wave, lane);
-            else load_q(kt + 1);
-        }
-        const char *At = cur, *Wt = cur + TILE32_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int c = kk * 2 + hi;
-            f16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *(const f16x8 *)(Wt + lds_off32(wf * 64 + i * 32 + l31, c));
-                b[i] = *(const f16x8 *)(At + lds_off32(wt * 64 + i * 32 + l31, c));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (WT != GW_F16 && more) dequant_half_block_to_lds<WT>(qn, sn, nxt + TILE32_BYTES, qrow, qhalf);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    }
-
-    // ---- epilogue in registers, then f16 tile -> LDS -> full-row stores
-    half_t *Cs = (half_t *)smem;                      // [128 tokens][16 chunks of 8 halfs], chunk ^ (tok & 15)
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int fl = wf * 64 + i * 32 + 8 * g + 4 * hi;       // feature within the tile
-            const int f0 = n0 + fl;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (f0 < p.N) bv = *(const f32x4 *)(p.bias + f0);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int tok = wt * 64 + j * 32 + l31;
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bv[e];
-                if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_tanh(v[e]);
-                }
-                if (EPI == EPI_BIAS_RESID) {
-                    if (f0 < p.N) {
-                        const f16x4 rv = *(const f16x4 *)(p.resid + ((size_t)m0 + tok) * p.N + f0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-                    }
-                }
-                f16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (_Float16)v[e];
-                *(f16x4 *)(Cs + tok * 128 + (((fl >> 3) ^ (tok & 15)) << 3) + (fl & 4)) = o;
-            }
-        }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const int idx = s * 256 + tid, tok = idx >> 4, chunk = idx & 15;
-        const int f0 = n0 + chunk * 8;
-        if (f0 < p.N)
-            *(uint4 *)(p.C + ((size_t)m0 + tok) * p.N + f0) = *(const uint4 *)(Cs + tok * 128 + ((chunk ^ (tok & 15)) << 3));
-    }
-}
-
-static int g_gemm_bk = 0;   // 0 = not read yet
-static int gemm_bk() {
-    if (!g_gemm_bk) {
-        const char *e = getenv("BERT_HIP_GEMM_BK");
-        g_gemm_bk = (e && atoi(e) == 32) ? 32 : 64;
-    }
-    return g_gemm_bk;
-}
-
 template <int WT>
 static void launch_wt(const GemmArgs &a, int grid, int epilogue, hipStream_t s) {
-    if (gemm_bk() == 32) {
-        switch (epilogue) {
-            case EPI_BIAS: hipLaunchKernelGGL((gemm_mfma32_kernel<WT, EPI_BIAS>), dim3(grid), dim3(256), 0, s, a); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_mfma32_kernel<WT, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
-            default: hipLaunchKernelGGL((gemm_mfma32_kernel<WT, EPI_BIAS_RESID>), dim3(grid), dim3(256), 0, s, a); break;
-        }
-        return;
-    }
     switch (epilogue) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_mfma_kernel<WT, EPI_BIAS>), dim3(grid), dim3(256), 0, s, a); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_mfma_kernel<WT, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;

@@ -81,17 +81,8 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
 bool gemm256_supported(const GemmWeight &W, int M_pad);
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
                     int epilogue, hipStream_t stream);
-// Whole FFN block + residual + LayerNorm in one kernel (ffn_fused.hip); y and out must differ.
-bool ffn_fused_supported(const GemmWeight &W1, const GemmWeight &W2);
-void launch_ffn_fused(const GemmWeight &W1, const GemmWeight &W2, const half_t *y, const float *b1, const float *b2,
-                      const float *gamma, const float *beta, half_t *out, int M_pad, hipStream_t stream);
-bool proj_ffn_fused_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
-void launch_proj_ffn_fused(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx,
-                           const half_t *x, const float *bo, const float *g1, const float *beta1, half_t *ybuf,
-                           const float *b1, const float *b2, const float *g2, const float *beta2, half_t *out, int M_pad,
-                           hipStream_t stream);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
-// GELU / down-projection); f16 weights, H = 256 / 384, W1 / W2 need w16p.
+// GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
@@ -108,11 +99,6 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
 // the last layer's LayerNorm 2: f32 rows -> f16 rows
 void launch_skinny_layernorm(const float *v, const float *gamma, const float *beta, half_t *out, int n_token_blocks, int H,
                              hipStream_t stream);
-// Row-panel kernels (panel_gemm.hip): out = LayerNorm(A W^T + bias + resid) * gamma + beta, and C = A W^T + bias.
-bool panel_gemm_supported(const GemmWeight &W, bool with_ln);
-void launch_proj_ln(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, const float *gamma,
-                    const float *beta, half_t *out, int M_pad, hipStream_t stream);
-void launch_panel_store(const GemmWeight &W, const half_t *A, const float *bias, half_t *out, int M_pad, hipStream_t stream);
 // Generic fallback (any K, N); needs W.naive16.
 void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
                        int M, int epilogue, hipStream_t stream);
@@ -132,14 +118,8 @@ bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_s
 void launch_attention_naive(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
                             int max_len, half_t *out, hipStream_t stream);
 
-// Q|K|V projection + attention of whole sentences in one kernel (qkv_attention.hip): x [T_pad][H] -> ctx [T_pad][H].
-// One workgroup per sentence; f16 weights, d_head 32, H <= 384, every sentence <= 128 tokens.
-bool qkv_attention_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);
-void launch_qkv_attention(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
-                          int n_sentences, int n_head, half_t *out, hipStream_t stream);
-
-// Second generation (qkv_attention2.hip): a workgroup owns a window of 128 token slots holding one or several whole
-// sentences (16-slot aligned); f16 weights, d_head 32, H = 128 / 256 / 384, every sentence <= 128 tokens.
+// Q|K|V projection + attention in one kernel (qkv_attention2.hip): x [T_pad][H] -> ctx [T_pad][H].  A workgroup owns a window
+// of 128 token slots holding one or several whole sentences (16-slot aligned); f16 or q4 weights, d_head 32, H = 128 / 256 / 384, every sentence <= 128 tokens.
 // `groups` [n_groups] = {first sentence, count} per window (device memory), or nullptr: the uniform rule
 // 128 / round_up(max_len, 16) sentences per window.
 bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);

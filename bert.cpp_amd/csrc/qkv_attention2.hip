@@ -1,5 +1,6 @@
 // qkv_attention2.hip — Q|K|V projection and self-attention of a 128-slot token WINDOW in one kernel (gfx950, d_head = 32,
-// f16 weights, H = 128 / 256 / 384).  Second generation of qkv_attention.hip (reference bert.cpp:822-856).
+// f16 or q4 weights, H = 128 / 256 / 384; reference bert.cpp:822-856).  (Its predecessor gave a workgroup ONE sentence and
+// paid for 128 tokens whatever the length; it is gone.)
 //
 // A workgroup owns a window of 128 token slots that holds one or SEVERAL whole sentences of the packed batch (each
 // starts at a multiple of 16 slots, see below), so batches of short sentences no longer fall back to the path that

@@ -46,111 +46,12 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     if (impl == 3) {
         if (!gemm256_supported(ws.w, M_pad)) return -2;
         launch_gemm256(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
-    } else if (impl == 2) {
-        if (epilogue != EPI_BIAS || !ws.mfma_ok || !panel_gemm_supported(ws.w, false)) return -2;
-        launch_panel_store(ws.w, dA.as<half_t>(), dB.as<float>(), dC.as<half_t>(), M_pad, nullptr);
     } else if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     else launch_gemm_naive(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M, epilogue, nullptr);
     CK(hipGetLastError());
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(C, dC.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
     return 0;
-}
-
-int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2, int32_t wtype,
-                          const float *b1, const float *b2, const float *gamma, const float *beta, int32_t fused,
-                          uint16_t *out) {
-    std::string err;
-    HostTensor t1, t2;
-    t1.type = wtype; t1.n_dims = 2; t1.ne0 = H; t1.ne1 = I; t1.data = (const uint8_t *)W1; t1.nbytes = wtype_row_bytes(wtype, H) * (size_t)I;
-    t2.type = wtype; t2.n_dims = 2; t2.ne0 = I; t2.ne1 = H; t2.data = (const uint8_t *)W2; t2.nbytes = wtype_row_bytes(wtype, I) * (size_t)H;
-    GemmWeightStore w1, w2;
-    if (!w1.build({&t1}, false, err) || !w2.build({&t2}, false, err)) { fprintf(stderr, "bert_hip_test_ffn: %s\n", err.c_str()); return -1; }
-    if (!w1.mfma_ok || !w2.mfma_ok) return -2;
-    if (fused && !ffn_fused_supported(w1.w, w2.w)) return -2;
-    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
-    DevBuf dy, dff, dout, db1, db2, dg, dbt;
-    if (!dy.alloc((size_t)M_pad * H * 2, err) || !dff.alloc((size_t)M_pad * I * 2, err) || !dout.alloc((size_t)M_pad * H * 2, err) ||
-        !db1.upload(b1, (size_t)I * 4, err) || !db2.upload(b2, (size_t)H * 4, err) || !dg.upload(gamma, (size_t)H * 4, err) ||
-        !dbt.upload(beta, (size_t)H * 4, err)) {
-        fprintf(stderr, "bert_hip_test_ffn: %s\n", err.c_str());
-        return -1;
-    }
-    CK(hipMemcpy(dy.p, y, (size_t)M * H * 2, hipMemcpyHostToDevice));
-    if (fused) {
-        launch_ffn_fused(w1.w, w2.w, dy.as<half_t>(), db1.as<float>(), db2.as<float>(), dg.as<float>(), dbt.as<float>(),
-                         dout.as<half_t>(), M_pad, nullptr);
-    } else {
-        launch_gemm_mfma(w1.w, dy.as<half_t>(), db1.as<float>(), nullptr, dff.as<half_t>(), M_pad, EPI_BIAS_GELU, nullptr);
-        launch_gemm_mfma(w2.w, dff.as<half_t>(), db2.as<float>(), dy.as<half_t>(), dout.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
-        launch_layernorm(dout.as<half_t>(), dg.as<float>(), dbt.as<float>(), M, H, nullptr);
-    }
-    CK(hipGetLastError());
-    CK(hipDeviceSynchronize());
-    CK(hipMemcpy(out, dout.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype, const float *bias,
-                              const uint16_t *resid, const float *gamma, const float *beta, int32_t fused, uint16_t *out) {
-    std::string err;
-    HostTensor t;
-    t.type = wtype; t.n_dims = 2; t.ne0 = K; t.ne1 = N; t.data = (const uint8_t *)W; t.nbytes = wtype_row_bytes(wtype, K) * (size_t)N;
-    GemmWeightStore ws;
-    if (!ws.build({&t}, false, err)) { fprintf(stderr, "bert_hip_test_proj_ln: %s\n", err.c_str()); return -1; }
-    if (!ws.mfma_ok || (fused && !panel_gemm_supported(ws.w, true))) return -2;
-    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
-    DevBuf dA, dR, dO, db, dg, dbt;
-    if (!dA.alloc((size_t)M_pad * K * 2, err) || !dR.alloc((size_t)M_pad * N * 2, err) || !dO.alloc((size_t)M_pad * N * 2, err) ||
-        !db.upload(bias, (size_t)N * 4, err) || !dg.upload(gamma, (size_t)N * 4, err) || !dbt.upload(beta, (size_t)N * 4, err)) {
-        fprintf(stderr, "bert_hip_test_proj_ln: %s\n", err.c_str());
-        return -1;
-    }
-    CK(hipMemcpy(dA.p, A, (size_t)M * K * 2, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dR.p, resid, (size_t)M * N * 2, hipMemcpyHostToDevice));
-    if (fused) {
-        launch_proj_ln(ws.w, dA.as<half_t>(), db.as<float>(), dR.as<half_t>(), dg.as<float>(), dbt.as<float>(), dO.as<half_t>(), M_pad, nullptr);
-    } else {
-        launch_gemm_mfma(ws.w, dA.as<half_t>(), db.as<float>(), dR.as<half_t>(), dO.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr);
-        launch_layernorm(dO.as<half_t>(), dg.as<float>(), dbt.as<float>(), M, N, nullptr);
-    }
-    CK(hipGetLastError());
-    CK(hipDeviceSynchronize());
-    CK(hipMemcpy(out, dO.p, (size_t)M * N * 2, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-// micro-benchmark: average ms of one fused-FFN launch on random data (weights f16), for kernel tuning
-BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters) {
-    std::string err;
-    std::vector<uint16_t> w1((size_t)I * H), w2((size_t)H * I), yv((size_t)M * H);
-    unsigned seed = 12345u;
-    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return (uint16_t)(0x2c00u | ((seed >> 9) & 0x83ffu)); };  // |x| in [0.06, 0.12)
-    for (auto &v : w1) v = rnd();
-    for (auto &v : w2) v = rnd();
-    for (auto &v : yv) v = (uint16_t)(rnd() + 0x1000u);
-    HostTensor t1, t2;
-    t1.type = W_F16; t1.n_dims = 2; t1.ne0 = H; t1.ne1 = I; t1.data = (const uint8_t *)w1.data(); t1.nbytes = w1.size() * 2;
-    t2.type = W_F16; t2.n_dims = 2; t2.ne0 = I; t2.ne1 = H; t2.data = (const uint8_t *)w2.data(); t2.nbytes = w2.size() * 2;
-    GemmWeightStore s1, s2;
-    if (!s1.build({&t1}, false, err) || !s2.build({&t2}, false, err) || !ffn_fused_supported(s1.w, s2.w)) return -1.f;
-    const int M_pad = (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
-    DevBuf dy, dout, dc;
-    std::vector<float> ones((size_t)I + H, 0.5f);
-    if (!dy.alloc((size_t)M_pad * H * 2, err) || !dout.alloc((size_t)M_pad * H * 2, err) || !dc.upload(ones.data(), ones.size() * 4, err)) return -1.f;
-    if (hipMemcpy(dy.p, yv.data(), yv.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -1.f;
-    hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
-    auto go = [&]() { launch_ffn_fused(s1.w, s2.w, dy.as<half_t>(), dc.as<float>(), dc.as<float>(), dc.as<float>(), dc.as<float>(), dout.as<half_t>(), M_pad, nullptr); };
-    for (int i = 0; i < 3; ++i) go();
-    hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) go();
-    hipEventRecord(e1, nullptr);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
-    return ms / iters;
 }
 
 int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
@@ -223,9 +124,6 @@ int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqle
                               dout.as<half_t>(), nullptr);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
-    } else if (fused) {
-        if (!qkv_attention_supported(ws.w, n_head, d_head, max_len)) return -2;
-        launch_qkv_attention(ws.w, dx.as<half_t>(), db.as<float>(), dcu.as<int32_t>(), n_sentences, n_head, dout.as<half_t>(), nullptr);
     } else {
         launch_gemm_mfma(ws.w, dx.as<half_t>(), db.as<float>(), nullptr, dqkv.as<half_t>(), T_pad, EPI_BIAS, nullptr);
         if (!launch_attention_mfma(dqkv.as<half_t>(), dcu.as<int32_t>(), n_sentences, n_head, d_head, max_len, dout.as<half_t>(), nullptr))
@@ -267,10 +165,6 @@ int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t
         if (!layer_tail_supported(wo.w, w1.w, w2.w)) return -2;
         launch_layer_tail(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
                           db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
-    } else if (impl == 2) {
-        if (!proj_ffn_fused_supported(wo.w, w1.w, w2.w)) return -2;
-        launch_proj_ffn_fused(wo.w, w1.w, w2.w, dc.as<half_t>(), dx.as<half_t>(), dbo.as<float>(), dg1.as<float>(), dbe1.as<float>(),
-                              dy.as<half_t>(), db1.as<float>(), db2.as<float>(), dg2.as<float>(), dbe2.as<float>(), dout.as<half_t>(), M_pad, nullptr);
     } else {
         // three GEMM kernels + two LayerNorm kernels
         DevBuf dff;

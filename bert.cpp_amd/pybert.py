@@ -28,8 +28,8 @@ BERT_HIP_H_SYMBOLS = [
 ]
 # include/bert_hip_test.h: the op-level test hooks, exported by libbert_test.so only
 BERT_HIP_TEST_H_SYMBOLS = [
-    "bert_hip_test_gemm", "bert_hip_test_proj_ln", "bert_hip_test_ffn", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
-    "bert_hip_test_layer_tail", "bert_hip_bench_ffn", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
+    "bert_hip_test_gemm", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
+    "bert_hip_test_layer_tail", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
     "bert_hip_test_build_windows_device", "bert_hip_test_max_windows",
     "bert_hip_test_dispatch", "bert_hip_test_shard_threads_created", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
     "bert_hip_test_model_digest",
@@ -107,10 +107,6 @@ def test_lib() -> C.CDLL:
     vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
-    L.bert_hip_test_proj_ln.restype = i32
-    L.bert_hip_test_proj_ln.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, i32, vp]
-    L.bert_hip_test_ffn.restype = i32
-    L.bert_hip_test_ffn.argtypes = [i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp]
     L.bert_hip_test_attention.restype = i32
     L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
     L.bert_hip_test_qkv_attention.restype = i32
@@ -426,36 +422,4 @@ def test_layer_tail(ctx: np.ndarray, x: np.ndarray, Wo_bytes, W1_bytes, W2_bytes
                                    ws[2].ctypes.data, wtype, *[p.ctypes.data for p in ps], impl, out.ctypes.data)
     if r != 0:
         raise RuntimeError(f"bert_hip_test_layer_tail failed: {r}")
-    return out
-
-
-def test_ffn(y: np.ndarray, W1_bytes: np.ndarray, W2_bytes: np.ndarray, wtype: int, I: int, b1, b2, gamma, beta,
-             fused: bool) -> np.ndarray:
-    L = test_lib()
-    y = np.ascontiguousarray(y, dtype=np.float16)
-    M, H = y.shape
-    w1 = np.ascontiguousarray(W1_bytes); w2 = np.ascontiguousarray(W2_bytes)
-    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    b1, b2, gamma, beta = f(b1), f(b2), f(gamma), f(beta)
-    out = np.zeros((M, H), dtype=np.float16)
-    r = L.bert_hip_test_ffn(M, H, I, y.ctypes.data, w1.ctypes.data, w2.ctypes.data, wtype, b1.ctypes.data, b2.ctypes.data,
-                            gamma.ctypes.data, beta.ctypes.data, int(fused), out.ctypes.data)
-    if r != 0:
-        raise RuntimeError(f"bert_hip_test_ffn failed: {r}")
-    return out
-
-
-def test_proj_ln(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias, resid, gamma, beta, fused: bool) -> np.ndarray:
-    L = test_lib()
-    A = np.ascontiguousarray(A, dtype=np.float16)
-    M, K = A.shape
-    wb = np.ascontiguousarray(W_bytes)
-    f = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    bias, gamma, beta = f(bias), f(gamma), f(beta)
-    resid = np.ascontiguousarray(resid, dtype=np.float16)
-    out = np.zeros((M, N), dtype=np.float16)
-    r = L.bert_hip_test_proj_ln(M, N, K, A.ctypes.data, wb.ctypes.data, wtype, bias.ctypes.data, resid.ctypes.data,
-                                gamma.ctypes.data, beta.ctypes.data, int(fused), out.ctypes.data)
-    if r != 0:
-        raise RuntimeError(f"bert_hip_test_proj_ln failed: {r}")
     return out

@@ -92,21 +92,22 @@ BERT_API int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id 
 BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
 BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
 
-/* Engine knobs (also settable through the environment before bert_load_from_file):
+/* Environment, read by bert_load_from_file (six switches):
  *   BERT_HIP_DEVICES       "all" or a comma-separated list of HIP ordinals without repeats: the GPUs of the context
  *                          (default: the calling thread's current device — one context, one GPU, unless asked otherwise)
- *   BERT_HIP_DEVICE        one ordinal (older spelling of BERT_HIP_DEVICES=<d>)
- *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
- *   BERT_HIP_GEMM          "mfma" (default) | "naive"  — kernel family for the weight mat-muls
- *   BERT_HIP_ATTN          "mfma" (default) | "naive"
+ *   BERT_HIP_KERNELS       "fused" (default): two launches per layer where the shape allows it — projection + attention of a
+ *                          128-slot window (qkv_attention2.hip), everything behind the attention (layer_tail.hip) —, tiled kernels
+ *                          elsewhere | "tiled": GEMM, attention and LayerNorm kernels only (Q|K|V and the intermediate through
+ *                          HBM) | "naive": the generic kernels (any shape; builds row-major f16 images at load)
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
- *                          at load (same values, fastest kernels) or stay 4-bit and are dequantised inside the GEMM kernels
- *   BERT_HIP_TAIL          1 (default) | 0 — one-launch kernel for out-projection + LN + FFN + LN (layer_tail.hip, f16 weights)
+ *                          at load, or stay 4-bit in HBM and are dequantised in the tile loads of the same kernels (same values,
+ *                          same bits on the fused kernels; a quarter of the weight bytes)
  *   BERT_HIP_LATENCY       1 (default) | 0 — batches of at most 128 tokens (one sentence per call, the reference's callers) take the
  *                          latency route: every mat-mul of a layer split over up to 192 workgroups (skinny.hip); same bits
- *   BERT_HIP_QKV_ATT       1 (default) | 0 — fused projection + attention kernels (sentences of up to 128 tokens)
- *   BERT_HIP_QKV2          1 (default) | 0 — their second generation (windows of whole sentences, qkv_attention2.hip)
- *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize                            */
+ *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
+ *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
+ * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
+ * of the fused family, "gemm" / "attn" = "mfma" | "naive", "chunk_tokens" = n.                                             */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);

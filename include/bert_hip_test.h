@@ -14,32 +14,20 @@ extern "C" {
 /* Standalone kernel entry points for op-level tests (host buffers in, host buffers out).
  * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
  * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
- * 2 bias+residual.  impl: 0 tiled MFMA kernel, 1 naive, 2 row-panel kernel (epilogue 0 only; -2 if the
- * shape is not supported), 3 the 256 x 256 tile kernel (gemm256.hip; -2 unless f16/f32 weights and N % 256 == 0).  Output f16 bits.  Returns 0 on success.                             */
+ * 2 bias+residual.  impl: 0 tiled MFMA kernel (gemm.hip; q4 blocks dequantised in the tile load), 1 naive, 3 the 256 x 256 tile
+ * kernel (gemm256.hip; -2 unless f16/f32 weights and N % 256 == 0).  Output f16 bits.  Returns 0 on success.                  */
 BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
                                     int32_t wtype, const float *bias, const uint16_t *resid,
                                     int32_t epilogue, int32_t impl, uint16_t *C);
-
-/* out = LayerNorm(A W^T + bias + resid) * gamma + beta (reference bert.cpp:859-875).  fused: 1 = single
- * row-panel kernel (-2 if unsupported), 0 = GEMM + LayerNorm kernels.                            */
-BERT_API int32_t bert_hip_test_proj_ln(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W, int32_t wtype,
-                                       const float *bias, const uint16_t *resid, const float *gamma,
-                                       const float *beta, int32_t fused, uint16_t *out);
-
-/* Whole feed-forward block: out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * gamma + beta, y [M][H] f16 bits,
- * W1 [I][H] and W2 [H][I] in file layout of `wtype`.  fused: 1 = single fused kernel (returns -2 if the
- * shape is not supported by it), 0 = the three-kernel path (GEMM+GELU, GEMM+residual, LayerNorm).   */
-BERT_API int32_t bert_hip_test_ffn(int32_t M, int32_t H, int32_t I, const uint16_t *y, const void *W1, const void *W2,
-                                   int32_t wtype, const float *b1, const float *b2, const float *gamma,
-                                   const float *beta, int32_t fused, uint16_t *out);
 
 /* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
 BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                          int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);
 
 /* Q|K|V projection + attention: x[T][H] f16 bits, Wqkv [3H][H] (Q rows, K rows, V rows) in file layout of `wtype`,
- * bias[3H] -> ctx[T][H] f16 bits (reference bert.cpp:822-856).  fused: 1 = one kernel per sentence
- * (qkv_attention.hip; -2 if the shape is not supported), 0 = GEMM kernel + attention kernel.       */
+ * bias[3H] -> ctx[T][H] f16 bits (reference bert.cpp:822-856).  fused: 0 = GEMM kernel + attention kernel; the window kernel
+ * (qkv_attention2.hip; -2 if the shape is not supported) with 2 = next-fit windows built on the host, 3 = the uniform
+ * placement rule, 4 = next-fit windows built on the device.                                                               */
 BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                              int32_t d_head, const uint16_t *x, const void *Wqkv, int32_t wtype,
                                              const float *bias, int32_t fused, uint16_t *out);
@@ -47,17 +35,13 @@ BERT_API int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t 
 /* Everything of a layer after the attention (reference bert.cpp:859-901):
  *   y = LayerNorm(ctx Wo^T + bo + x) * g1 + be1;  out = LayerNorm(gelu(y W1^T + b1) W2^T + b2 + y) * g2 + be2
  * ctx, x, out [M][H] f16 bits; Wo [H][H], W1 [I][H], W2 [H][I] in file layout of `wtype`.
- * impl: 0 = GEMM + LayerNorm kernels, 1 = the one-launch kernel with specialist wave pairs (layer_tail.hip), 2 = panel kernel
- * (ffn_fused.hip with the leading projection phase); -2 if the shape is not supported by the chosen kernel.   */
+ * impl: 0 = GEMM + LayerNorm kernels, 1 = the one-launch kernel with specialist wave pairs (layer_tail.hip; -2 if the shape is
+ * not supported).  q4 `wtype`: both keep the blocks 4-bit on the device and dequantise in the tile load.             */
 BERT_API int32_t bert_hip_test_layer_tail(int32_t M, int32_t H, int32_t I, const uint16_t *ctx, const uint16_t *x,
                                           const void *Wo, const void *W1, const void *W2, int32_t wtype,
                                           const float *bo, const float *g1, const float *be1, const float *b1,
                                           const float *b2, const float *g2, const float *be2, int32_t impl,
                                           uint16_t *out);
-
-/* Average milliseconds of `iters` launches of the fused feed-forward kernel on device-resident random data
- * (tuning helper of tools/bench_ffn.py; negative on error).                                              */
-BERT_API float bert_hip_bench_ffn(int32_t M, int32_t H, int32_t I, int32_t iters);
 
 /* Embedding gather-sum + LayerNorm (reference bert.cpp:796-814): tables in the file layout of `table_type` (0 f32, 1 f16,
  * 2 q4_0, 3 q4_1), word [n_vocab][H], type [2][H], pos [n_pos][H]; packed sentences; out [T][H] f16 bits.               */

@@ -41,7 +41,7 @@ def _gelu(x):
     return 0.5 * x * (1 + np.tanh(0.7978845608028654 * x * (1 + 0.044715 * x * x)))
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3], ids=["mfma", "naive", "panel", "tile256"])
+@pytest.mark.parametrize("impl", [0, 1, 3], ids=["mfma", "naive", "tile256"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1", "f32"])
 @pytest.mark.parametrize("shape", [(200, 192, 128), (256, 384, 384), (130, 64, 64), (512, 1536, 384), (384, 384, 1536),
                                    (256, 1152, 384), (129, 2304, 768), (300, 768, 3072), (513, 3072, 768), (256, 256, 64)])
@@ -57,12 +57,12 @@ def test_gemm_kernel(impl, ftype, shape):
     resid = rng.normal(0, 1, (M, N)).astype(np.float16)
     wb, wdeq = _weight_bytes(W, ftype)
     base = A.astype(np.float64) @ wdeq.astype(np.float64).T + bias
-    for epi in ((0,) if impl == 2 else (0, 1, 2)):      # (the row-panel kernel has the plain epilogue only)
+    for epi in (0, 1, 2):
         want = base if epi == 0 else _gelu(base) if epi == 1 else base + resid.astype(np.float64)
         try:
             got = pybert.test_gemm(A, wb, WT[ftype], N, bias, resid if epi == 2 else None, epi, impl).astype(np.float64)
         except RuntimeError as e:
-            if impl in (2, 3) and "-2" in str(e):
+            if impl == 3 and "-2" in str(e):
                 pytest.skip("shape / weight type not handled by this kernel")
             raise
         err = np.abs(got - want)
@@ -92,63 +92,10 @@ def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
         assert not bad.any(), (impl, epi, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["panel", "gemm+ln"])
-@pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1"])
-@pytest.mark.parametrize("M,N,K", [(200, 128, 64), (256, 384, 384), (130, 256, 512), (384, 384, 1536)])
-def test_proj_layernorm_kernel(fused, ftype, M, N, K):
-    """LayerNorm(A W^T + b + resid) * gamma + beta: row-panel kernel and GEMM + LayerNorm path vs numpy."""
-    rng = np.random.default_rng(M + N + K)
-    A = rng.normal(0, 1, (M, K)).astype(np.float16)
-    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float32)
-    W[:, : K // 2] *= 1.5; W[: N // 3] += 0.02
-    bias = rng.normal(0, 0.5, N).astype(np.float32)
-    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
-    gamma = rng.normal(1, 0.2, N).astype(np.float32); beta = rng.normal(0, 0.3, N).astype(np.float32)
-    wb, wd = _weight_bytes(W, ftype)
-    got = pybert.test_proj_ln(A, wb, WT[ftype], N, bias, resid, gamma, beta, fused).astype(np.float64)
-    pre = A.astype(np.float64) @ wd.astype(np.float64).T + bias + resid.astype(np.float64)
-    mu = pre.mean(axis=1, keepdims=True)
-    want = (pre - mu) / np.sqrt(((pre - mu) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta
-    err = np.abs(got - want)
-    assert err.max() < 1.5e-2, (fused, ftype, M, N, K, float(err.max()), np.argwhere(err > 1.5e-2)[:5])
-    assert err.mean() < 1.5e-3
-
-
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "three-kernel"])
-@pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1"])
-@pytest.mark.parametrize("M,H,I", [(200, 128, 128), (256, 256, 512), (130, 384, 1536), (384, 384, 256)])
-def test_ffn_block_kernel(fused, ftype, M, H, I):
-    """gelu(y W1^T + b1) W2^T + b2 + y -> LayerNorm, fused kernel and three-kernel path vs numpy."""
-    rng = np.random.default_rng(M + H + I)
-    y = rng.normal(0, 1, (M, H)).astype(np.float16)
-    W1 = (rng.normal(0, 1, (I, H)) / np.sqrt(H)).astype(np.float32)
-    W2 = (rng.normal(0, 1, (H, I)) / np.sqrt(I)).astype(np.float32)
-    W1[:, : H // 2] *= 1.5; W2[: H // 3] += 0.02
-    b1 = rng.normal(0, 0.5, I).astype(np.float32); b2 = rng.normal(0, 0.5, H).astype(np.float32)
-    gamma = rng.normal(1, 0.2, H).astype(np.float32); beta = rng.normal(0, 0.3, H).astype(np.float32)
-    w1b, w1d = _weight_bytes(W1, ftype)
-    w2b, w2d = _weight_bytes(W2, ftype)
-    try:
-        got = pybert.test_ffn(y, w1b, w2b, WT[ftype], I, b1, b2, gamma, beta, fused).astype(np.float64)
-    except RuntimeError as e:
-        if fused and "-2" in str(e):
-            pytest.skip("shape / weight type not handled by the fused kernel (falls back to three kernels)")
-        raise
-    y64 = y.astype(np.float64)
-    h = _gelu(y64 @ w1d.astype(np.float64).T + b1)
-    pre = h @ w2d.astype(np.float64).T + b2 + y64
-    mu = pre.mean(axis=1, keepdims=True)
-    want = (pre - mu) / np.sqrt(((pre - mu) ** 2).mean(axis=1, keepdims=True) + 1e-5) * gamma + beta
-    err = np.abs(got - want)
-    assert err.max() < 2.5e-2, (fused, ftype, M, H, I, float(err.max()), np.argwhere(err > 2.5e-2)[:5])
-    assert err.mean() < 2.5e-3
-
-
-@pytest.mark.parametrize("impl", [1, 2], ids=["wave-pairs", "panel"])
 @pytest.mark.parametrize("M,H,I", [(200, 128, 256), (256, 256, 512), (130, 384, 1536), (384, 384, 256), (128, 128, 128), (1000, 256, 1024)])
-def test_layer_tail_kernel(impl, M, H, I):
-    """Out-projection + LN + FFN + LN in one launch (layer_tail.hip / ffn_fused.hip) against a float64 reference of
-    reference bert.cpp:859-901 and against the five-kernel path."""
+def test_layer_tail_kernel(M, H, I, impl=1):
+    """Out-projection + LN + FFN + LN in one launch (layer_tail.hip) and as five kernels (three GEMMs, two LayerNorms: the
+    path of the shapes the one-launch kernel does not take) against a float64 reference of reference bert.cpp:859-901."""
     rng = np.random.default_rng(M + H + I)
     ctx = rng.normal(0, 1, (M, H)).astype(np.float16)
     x = rng.normal(0, 1, (M, H)).astype(np.float16)
@@ -173,15 +120,18 @@ def test_layer_tail_kernel(impl, M, H, I):
     want = ln(f8(gl.astype(np.float16)) @ f8(W2).T + b2 + y16, g2, be2)
 
     args = (ctx, x, Wo.view(np.uint8), W1.view(np.uint8), W2.view(np.uint8), 1, I, bo, g1, be1, b1, b2, g2, be2)
+    base = pybert.test_layer_tail(*args, 0).astype(np.float64)
+    err = np.abs(base - want)
+    assert err.max() < 2.5e-2 and err.mean() < 2e-3, ("five kernels", M, H, I, float(err.max()), float(err.mean()))
     try:
         got = pybert.test_layer_tail(*args, impl).astype(np.float64)
     except RuntimeError as e:
         if "-2" in str(e):
-            pytest.skip("shape not handled by this kernel (the engine falls back)")
+            assert H not in (256, 384)                   # (the engine falls back to the five kernels)
+            return
         raise
     err = np.abs(got - want)
     assert err.max() < 2.5e-2 and err.mean() < 2e-3, (impl, M, H, I, float(err.max()), float(err.mean()))
-    base = pybert.test_layer_tail(*args, 0).astype(np.float64)
     assert np.abs(got - base).max() < 2.5e-2
 
 
@@ -259,53 +209,6 @@ def test_attention_kernel(impl, d_head, n_head, lens):
     got = pybert.test_attention(qkv, cu, n_head, d_head, impl).astype(np.float64)
     err = np.abs(got - want)
     assert err.max() < 6e-3, (impl, d_head, lens, float(err.max()), np.argwhere(err > 6e-3)[:5])
-
-
-@pytest.mark.parametrize("n_head", [2, 4, 12])
-@pytest.mark.parametrize("lens", [[128, 128, 128], [1, 2, 5, 31, 32, 33, 64, 100, 127, 128], [96, 97, 48]])
-def test_qkv_attention_fused_kernel(n_head, lens):
-    """Projection + attention of whole sentences in one kernel (qkv_attention.hip) against the two-kernel path
-    (same arithmetic: equal bits) and against a float64 reference of reference bert.cpp:822-856."""
-    d_head, H = 32, 32 * n_head
-    rng = np.random.default_rng(sum(lens) + n_head)
-    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    T = int(cu[-1])
-    x = rng.normal(0, 1, (T, H)).astype(np.float16)
-    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float16)
-    W[:H] *= 1.7
-    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
-    fused = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, True)
-    split = pybert.test_qkv_attention(x, cu, n_head, d_head, W.view(np.uint8), 1, bias, False)
-    assert np.array_equal(fused.view(np.uint16), split.view(np.uint16))
-    qkv = (x.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float16)
-    want = _attention_ref(qkv, cu, n_head, d_head)
-    err = np.abs(fused.astype(np.float64) - want)
-    assert err.max() < 6e-3, (n_head, lens, float(err.max()))
-
-
-@pytest.mark.parametrize("wtype", [2, 3])
-@pytest.mark.parametrize("n_head,lens", [(4, [128, 1, 77, 5]), (8, [33, 128, 64] * 3), (12, [128, 2, 99, 31, 128])])
-def test_qkv_attention_fused_kernel_q4(n_head, lens, wtype):
-    """q4_0 / q4_1 weights in the fused kernel: blocks fetched to registers and dequantised into the projection waves'
-    private tiles — the same dequantisation and accumulation order as the panel kernel (equal bits), and within f16
-    rounding of a float64 reference computed from the dequantised weights (oracle rule, reference ggml.c:734-790)."""
-    d_head, H = 32, 32 * n_head
-    rng = np.random.default_rng(sum(lens) + n_head + wtype)
-    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
-    T = int(cu[-1])
-    x = rng.normal(0, 1, (T, H)).astype(np.float16)
-    W = (rng.normal(0, 1, (3 * H, H)) / np.sqrt(H)).astype(np.float32)
-    W[:H] *= 1.7
-    bias = rng.normal(0, 0.3, 3 * H).astype(np.float32)
-    q = gf.quantize_q4_0(W) if wtype == 2 else gf.quantize_q4_1(W)
-    Wd = (gf.dequantize_q4_0(q) if wtype == 2 else gf.dequantize_q4_1(q)).reshape(W.shape)
-    fused = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, True)
-    split = pybert.test_qkv_attention(x, cu, n_head, d_head, q.view(np.uint8), wtype, bias, False)
-    assert np.array_equal(fused.view(np.uint16), split.view(np.uint16))
-    qkv = (x.astype(np.float64) @ Wd.astype(np.float64).T + bias).astype(np.float16)
-    want = _attention_ref(qkv, cu, n_head, d_head)
-    err = np.abs(fused.astype(np.float64) - want)
-    assert err.max() < 1e-2, (n_head, lens, float(err.max()))
 
 
 Q2_CASES = [
@@ -411,20 +314,20 @@ def test_qkv_attention2_same_bits_in_any_window():
             assert np.array_equal(got[i].view(np.uint16), alone[i].view(np.uint16)), (order, i)
 
 
-def test_qkv_attention_fused_kernel_limits():
+def test_qkv_attention2_kernel_limits():
     rng = np.random.default_rng(0)
     H = 128
     x = rng.normal(0, 1, (130, H)).astype(np.float16)
     W = rng.normal(0, 0.1, (3 * H, H)).astype(np.float32)
     bias = np.zeros(3 * H, np.float32)
     cu = np.array([0, 130], np.int32)
-    with pytest.raises(RuntimeError, match="-2"):                      # longer than one workgroup's 128 tokens
-        pybert.test_qkv_attention(x, cu, 4, 32, W.astype(np.float16).view(np.uint8), 1, bias, True)
+    with pytest.raises(RuntimeError, match="-2"):                      # longer than a window's 128 slots
+        pybert.test_qkv_attention(x, cu, 4, 32, W.astype(np.float16).view(np.uint8), 1, bias, 2)
     H = 192
     q = gf.quantize_q4_0(rng.normal(0, 0.1, (3 * H, H)).astype(np.float32))
-    with pytest.raises(RuntimeError, match="-2"):                      # q4: an even number of 64-wide k-tiles only
+    with pytest.raises(RuntimeError, match="-2"):                      # H = 128 / 256 / 384 only
         pybert.test_qkv_attention(rng.normal(0, 1, (64, H)).astype(np.float16), np.array([0, 64], np.int32), 6, 32,
-                                  q.view(np.uint8), 2, np.zeros(3 * H, np.float32), True)
+                                  q.view(np.uint8), 2, np.zeros(3 * H, np.float32), 2)
 
 
 def test_attention_generic_head_dim():
@@ -656,7 +559,7 @@ def test_encode_equals_tokenize_plus_eval(make_model, tmp_path):
 @pytest.mark.parametrize("dims,ftype", [("tiny-h128", "q4_0"), ("tiny-d64", "q4_1"), ("minilm-l6", "q4_0"), ("tiny", "q4_1")])
 def test_q4_expanded_at_load_equals_fused_dequant(make_model, dims, ftype, monkeypatch):
     """q4 weight matrices are expanded to f16 images once at load by default (BERT_HIP_Q4=expand) and then run the
-    f16 kernels; BERT_HIP_Q4=fused keeps the 4-bit planes and dequantises inside the GEMM kernels.  Same weight
+    f16 kernels; BERT_HIP_Q4=fused keeps the 4-bit planes and dequantises in the kernels' tile loads.  Same weight
     values either way: the embeddings agree to f16-accumulation-order noise and both match the oracle."""
     path, hp = make_model(dims, ftype, 5)
     rng = np.random.default_rng(3)
@@ -667,10 +570,13 @@ def test_q4_expanded_at_load_equals_fused_dequant(make_model, dims, ftype, monke
     b = pybert.BertModel(path).eval_batch(sents)
     monkeypatch.delenv("BERT_HIP_Q4")
     ref = orc.Oracle(path)
+    if dims == "minilm-l6":
+        # the window kernel and the layer tail expand the blocks into the tile image the default path loads: the same bits
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
     for i, s in enumerate(sents):
         assert cosine(a[i], b[i]) > 1 - 2e-5, (i, cosine(a[i], b[i]))
         want = ref.eval(s)
-        assert cosine(a[i], want) > 0.99 and cosine(b[i], want) > 0.99
+        assert cosine(a[i], want) >= TIGHT_COS_GGML[ftype] and cosine(b[i], want) >= TIGHT_COS_GGML[ftype]
 
 
 @pytest.mark.parametrize("ftype", ["q4_0", "q4_1"])
@@ -712,26 +618,33 @@ def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype):
     assert cosine(alone[3], want) >= TIGHT_COS_GGML[ftype]
 
 
-@pytest.mark.parametrize("knob", ["BERT_HIP_TAIL", "BERT_HIP_QKV_ATT", "BERT_HIP_LAYER_FUSED+BERT_HIP_TAIL",
-                                  "BERT_HIP_PANEL+BERT_HIP_TAIL+BERT_HIP_QKV_ATT"])
-def test_kernel_families_agree_end_to_end(make_model, knob, monkeypatch):
-    """The fused kernels each have a fallback family (one-launch layer tail -> 128-token panel kernels -> tiled GEMMs
-    + LayerNorm kernels; fused projection+attention -> QKV GEMM + attention kernel).  On the benchmark's dimensions
-    every family must give the same embeddings up to accumulation-order noise, and match the oracle."""
-    path, hp = make_model("minilm-l6", "f16", 2)
+@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
+@pytest.mark.parametrize("knob", ["tail=0", "qkv2=0", "kernels=tiled", "kernels=naive"])
+def test_kernel_families_agree_end_to_end(make_model, knob, ftype, monkeypatch):
+    """The two fused kernels each have a fallback: the one-launch layer tail -> tiled GEMMs + LayerNorm kernels, the window
+    kernel (projection + attention) -> QKV GEMM + attention kernel; BERT_HIP_KERNELS=tiled takes both, =naive the generic
+    kernels.  On the benchmark's dimensions every family must give the same embeddings up to accumulation-order noise, and
+    match the oracle; q4 files with the blocks kept 4-bit on the device (every family dequantises in its tile load)."""
+    path, hp = make_model("minilm-l6", ftype, 2)
     rng = np.random.default_rng(4)
     sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (128, 128, 96, 128, 77, 128)]
+    if ftype != "f16":
+        monkeypatch.setenv("BERT_HIP_Q4", "fused")
     base = pybert.BertModel(path).eval_batch(sents)
-    for k in knob.split("+"):
-        monkeypatch.setenv(k.split("=")[0], k.split("=")[1] if "=" in k else "0")
-    m_alt = pybert.BertModel(path)
+    key, value = knob.split("=")
+    if key == "kernels":
+        monkeypatch.setenv("BERT_HIP_KERNELS", value)
+        m_alt = pybert.BertModel(path)
+        monkeypatch.delenv("BERT_HIP_KERNELS")
+    else:
+        m_alt = pybert.BertModel(path)
+        m_alt.set_option(key, value)
     alt = m_alt.eval_batch(sents)
     m_alt.profile(True); m_alt.eval_batch(sents); names = set(m_alt.profile_report()); m_alt.profile(False)
-    assert ("layer_tail" in names) == ("BERT_HIP_TAIL" not in knob), (knob, names)
-    for k in knob.split("+"):
-        monkeypatch.delenv(k.split("=")[0])
+    assert ("layer_tail" in names) == (knob == "qkv2=0"), (knob, names)
+    assert ("qkv_attention2" in names) == (knob == "tail=0"), (knob, names)
     want = orc.Oracle(path).eval(sents[2])
-    assert cosine(base[2], want) > 1 - 1e-4 and cosine(alt[2], want) > 1 - 1e-4
+    assert cosine(base[2], want) >= TIGHT_COS_GGML[ftype] and cosine(alt[2], want) >= TIGHT_COS_GGML[ftype]
     for i in range(len(sents)):
         assert cosine(base[i], alt[i]) > 1 - 1e-6, (knob, i, cosine(base[i], alt[i]))
 
@@ -784,11 +697,14 @@ def test_full_size_batch_properties_bert_base(make_model):
     assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample[:2]) >= TIGHT_COS_PLAIN
 
 
-@pytest.mark.parametrize("ftype,B", [("f16", 256), ("q4_0", 1024)])
-def test_full_size_batch_properties(make_model, ftype, B):
+@pytest.mark.parametrize("ftype,B,q4", [("f16", 256, None), ("q4_0", 1024, "expand"), ("q4_0", 1024, "fused")])
+def test_full_size_batch_properties(make_model, ftype, B, q4, monkeypatch):
     """configs[1] / configs[2]: MiniLM-L6 dims, seq_len 128.  Unit norm, duplicate sentences give
-    identical bits wherever they sit, and a sample agrees with the oracle."""
+    identical bits wherever they sit, and a sample agrees with the oracle.  configs[2] both ways: the q4 matrices expanded
+    to f16 at load (the default), and as written — 4-bit in HBM, dequantised in the tile loads of the same two kernels."""
     path, hp = make_model("minilm-l6", ftype, 0)
+    if q4:
+        monkeypatch.setenv("BERT_HIP_Q4", q4)
     m = pybert.BertModel(path)
     ids = gf.synthetic_token_ids(B, 128, hp.n_vocab, seed=1234 + (1 if ftype == "f16" else 2))
     ids[B // 2] = ids[3]
@@ -798,8 +714,7 @@ def test_full_size_batch_properties(make_model, ftype, B):
     out = m.eval_packed(ids.reshape(-1), cu)
     rep = m.profile_report()
     m.profile(False)
-    # two launches per layer: the fused projection + attention kernel and the token-owning layer tail (q4 matrices are
-    # expanded to f16 at load by default, so both models take the same kernels)
+    # two launches per layer: the fused projection + attention kernel and the token-owning layer tail, whatever the weights
     assert set(rep) == {"embed_ln", "qkv_attention2", "layer_tail", "pool_normalize"}, sorted(rep)
     assert rep["qkv_attention2"]["launches"] == hp.n_layer and rep["layer_tail"]["launches"] == hp.n_layer
     assert np.isfinite(out).all()

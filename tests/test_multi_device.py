@@ -143,7 +143,7 @@ class _Hip:
 @pytest.mark.gpu
 def test_gather_entry_point_matches_the_host_api(make_model, monkeypatch):
     """bert_hip_eval_packed_gather on the devices of this box (one on the test box): the device-resident matrix equals the
-    host API's result bit for bit; with BERT_HIP_RCCL_SINGLE=1 the exchange runs through a 1-rank RCCL communicator."""
+    host API's result bit for bit; with the option test_rccl_single the exchange runs through a 1-rank RCCL communicator."""
     hip = _Hip()
     path, hp = make_model("minilm-l6", "f16", 0)
     rng = np.random.default_rng(3)
@@ -153,7 +153,7 @@ def test_gather_entry_point_matches_the_host_api(make_model, monkeypatch):
     m = pybert.BertModel(path)
     want = m.eval_packed(toks, cu)
     for force in ("0", "1"):
-        monkeypatch.setenv("BERT_HIP_RCCL_SINGLE", force)
+        m.set_option("test_rccl_single", force)
         ptrs = m.eval_packed_gather(toks, cu)
         assert len(ptrs) == m.n_devices() >= 1
         for d, p in enumerate(ptrs):
@@ -223,9 +223,8 @@ def test_device_api_packs_short_sentences_like_the_host_api(make_model, mean_len
 def test_no_exception_crosses_the_abi(make_model, capfd, monkeypatch):
     path, hp = make_model("tiny", "f16", 1)
     s = np.arange(5, dtype=np.int32)
-    monkeypatch.setenv("BERT_HIP_INJECT_BAD_ALLOC", "1")    # (read once, when a model is loaded)
     m = pybert.BertModel(path)
-    monkeypatch.delenv("BERT_HIP_INJECT_BAD_ALLOC")
+    m.set_option("test_inject_bad_alloc", "1")
     out = m.eval_batch([s, s])
     assert np.isnan(out).all()                              # outputs untouched, the process is alive
     assert "bert_eval_batch: std::bad_alloc" in capfd.readouterr().err
@@ -246,13 +245,15 @@ def test_gemm_option_toggled_after_load(make_model, capfd, monkeypatch):
     m.set_option("gemm", "naive")
     assert "ignored" in capfd.readouterr().err
     assert np.array_equal(m.eval_batch(s), base)
-    monkeypatch.setenv("BERT_HIP_GEMM", "naive")
+    monkeypatch.setenv("BERT_HIP_KERNELS", "naive")
     m2 = pybert.BertModel(path)
-    monkeypatch.delenv("BERT_HIP_GEMM")
+    monkeypatch.delenv("BERT_HIP_KERNELS")
     naive = m2.eval_batch(s)
     m2.set_option("gemm", "mfma")
+    m2.set_option("attn", "mfma")
     fast = m2.eval_batch(s)
     m2.set_option("gemm", "naive")
+    m2.set_option("attn", "naive")
     assert np.array_equal(m2.eval_batch(s), naive)
     for a, b in zip(naive, fast):
         assert float(a @ b) > 1 - 1e-5

@@ -11,10 +11,9 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-NAMES = {"qkv_attention_kernel": "qkv_attention", "qkv_attention2_kernel": "qkv_attention2", "layer_tail_kernel": "layer_tail",
-         "ffn_fused_kernel": "proj_ffn_fused", "panel_store_kernel": "panel_qkv", "attention_mfma_kernel": "attention",
+NAMES = {"qkv_attention2_kernel": "qkv_attention2", "layer_tail_kernel": "layer_tail", "attention_mfma_kernel": "attention",
          "embed_ln_kernel": "embed_ln", "embed_ln_rows_kernel": "embed_ln", "pool_normalize_kernel": "pool_normalize",
-         "proj_ln_kernel": "proj_ln", "layernorm_rows_kernel": "layernorm",
+         "layernorm_rows_kernel": "layernorm",
          # gemm256_kernel<EPI>: 0 = bias (Q|K|V), 1 = bias + GELU (FFN up), 2 = bias + residual (attention output AND FFN down:
          # one kernel, two shapes; their mean is booked under gemm_ffn_down)
          "gemm256_kernel<0>": "gemm_qkv", "gemm256_kernel<1>": "gemm_ffn_up", "gemm256_kernel<2>": "gemm_ffn_down"}
