@@ -49,6 +49,7 @@ struct Gemm256Args {
     const half_t *resid;    // [M_pad][N] or null
     half_t *C;              // [M_pad][N]
     int N, K, n_tiles_n, n_tiles;
+    int n_groups;           // feature-tile groups an XCD pair / quad shares the walk with (1: every XCD walks all feature tiles)
 };
 
 }  // namespace
@@ -118,11 +119,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int K = p.K, nk = K / G2_BK;
 
-    // ---- this workgroup's output tiles: t_first, t_first + S, ... below t_end
+    // ---- this workgroup's output tiles: t_first, t_first + S, ... below t_end, in the XCD's own numbering.  An XCD walks a
+    // contiguous range of token tiles and, of each, the feature tiles n_begin .. n_begin + cnt_n back to back (an activation
+    // tile comes from HBM once per XCD that needs it).  n_groups = 1: cnt_n = all of them, the ranges are cut at tile
+    // granularity.  n_groups = G > 1 (weight matrices that do not fit an XCD's 4 MiB L2 beside the activation tiles in flight:
+    // the up-projection of the H = 768 models, 4.5 MiB): XCD x takes feature group x % G — its slice of W stays in its L2 —
+    // and token range x / G of 8 / G; the activations are read G times (from the memory-side cache after the first).
     const int xcd = blockIdx.x & 7, S = gridDim.x >> 3;
-    const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
-    const int t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
+    const int G = p.n_groups, cnt_n = p.n_tiles_n / G, n_begin = (xcd % G) * cnt_n;
+    int t_begin, t_end;
+    if (G == 1) {
+        const int q8 = p.n_tiles >> 3, r8 = p.n_tiles & 7;
+        t_begin = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        t_end = t_begin + q8 + (xcd < r8 ? 1 : 0);
+    } else {
+        const int R = 8 / G, r = xcd / G, tm = p.n_tiles / p.n_tiles_n, q = tm / R, rem = tm % R;
+        const int m_begin = r < rem ? r * (q + 1) : rem * (q + 1) + (r - rem) * q;
+        t_begin = m_begin * cnt_n;
+        t_end = t_begin + (q + (r < rem ? 1 : 0)) * cnt_n;
+    }
     int tile = t_begin + (int)(blockIdx.x >> 3);
     if (tile >= t_end) return;
 
@@ -271,7 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // (a one-time start delay that spreads the workgroups' phases over a tile period was tried: no gain — the cost of an
     // epilogue is its CU's own store issue, 31 B/cycle/CU into L2 and 18 when the whole chip streams to HBM,
     // tools/ubench/store_issue.hip — not the other CUs' bursts)
-    int m0 = (tile / p.n_tiles_n) * G2_BM, n0 = (tile % p.n_tiles_n) * G2_BN;
+    int m0 = (tile / cnt_n) * G2_BM, n0 = (n_begin + tile % cnt_n) * G2_BN;
     {   // the first reduction tile of the first output tile
         const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
         dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         const bool more = next < t_end;
         // (after the last output tile the stream requests this tile's first reduction tile once more: a request that
         // is never read costs less than a branch around every request)
-        const int nm0 = more ? (next / p.n_tiles_n) * G2_BM : m0, nn0 = more ? (next % p.n_tiles_n) * G2_BN : n0;
+        const int nm0 = more ? (next / cnt_n) * G2_BM : m0, nn0 = more ? (n_begin + next % cnt_n) * G2_BN : n0;
         const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
         {   // ---- reduction tile 0: the previous output tile is finished behind its barrier
             g2_tile_barrier(f1);
@@ -362,6 +377,11 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C;
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
     a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
+    // feature groups: only where W (N x K f16) overflows an XCD's L2 share and reading the activations twice is the cheaper
+    // side (K small against N), with enough token tiles for the 8 / G token ranges to balance
+    // (measured, bert-base / mpnet dimensions: up-projection -2.5 %; FETCH_SIZE per launch in profiles/)
+    a.n_groups = 1;
+    if ((size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G2_BM >= 64) a.n_groups = 2;
     // one persistent workgroup per CU (256 on an MI355X, a multiple of the 8 XCDs), fewer when there are fewer tiles
     static int n_cu[MAX_HIP_DEVICES] = {};
     int dev = 0;

@@ -71,7 +71,7 @@ def test_gemm_kernel(impl, ftype, shape):
         assert not bad.any(), (ftype, shape, epi, impl, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5])
 
 
-@pytest.mark.parametrize("M,N,K", [(20480, 2304, 768), (33000, 768, 3072), (70000, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(20480, 2304, 768), (33000, 768, 3072), (70000, 768, 768), (20000, 3072, 768), (16640, 1536, 384)])
 def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
     """The 256 x 256 tile kernel runs one persistent workgroup per CU: with more output tiles than CUs a workgroup streams
     its reduction tiles across output tiles and finishes a tile's epilogue behind the next tile's first barrier.
