@@ -36,8 +36,10 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
 }
 
 // NT threads: 256 (4 waves), or 512 for long sentences (their K / V^T fill most of the CU's LDS, so one workgroup is all
-// a CU holds: 8 waves = two per SIMD let one wave's softmax run under the other's MFMAs)
-template <int D, int NT>
+// a CU holds: 8 waves = two per SIMD let one wave's softmax run under the other's MFMAs).  CH = keys per online-softmax
+// step.  (Sixteen waves with 64-key steps — four per SIMD within 128 registers — were measured at 512 x 512 tokens: 3 %
+// SLOWER than eight with 128-key steps; the counters of that shape: MFMA busy 27 %, VALU issue ~21 %, the rest waits.)
+template <int D, int NT, int CH>
 __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__restrict__ qkv,
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,
                                                              half_t *__restrict__ out) {
@@ -69,20 +71,45 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
         for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
     }
 
-    // ---- stage K (swizzled rows) and V^T (transposed) of this head; zero the padding
+    // ---- stage K (swizzled rows) and V^T (transposed) of this head; zero the padding.  A thread takes 16-byte chunk c of the
+    // row PAIR (2 rp, 2 rp + 1): V^T then goes out as 4-byte stores (two keys of one feature), half as many as row by row.
+    // EVERY load of a thread is in flight before its first LDS store (a long sentence's workgroup is alone on its CU: one
+    // HBM round trip per loop iteration — the rolled form — was most of the kernel's time at 512 tokens).
     constexpr int CPR = D / 8;                         // 16-byte chunks per row
-    for (int idx = tid; idx < n_pad * CPR; idx += NT) {
-        const int row = idx / CPR, c = idx % CPR;
-        uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-        if (row < n) {
-            const half_t *base = qkv + (size_t)(tok0 + row) * ld + h * D + c * 8;
-            kv = *(const uint4 *)(base + H);
-            vv = *(const uint4 *)(base + 2 * H);
-        }
-        *(uint4 *)(Ks + k_off<D>(row, c)) = kv;
-        const f16x8 v8 = __builtin_bit_cast(f16x8, vv);
+    {
+        const int total = (n_pad / 2) * CPR;
+        constexpr int UNR = 4;                         // row pairs in flight per thread: 16 loads of 16 bytes
+        for (int base = tid; base < total; base += NT * UNR) {
+            uint4 kv[UNR][2], vv[UNR][2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) Vt[(c * 8 + e) * vt_ld + row] = v8[e];
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    kv[u][w] = uint4{0, 0, 0, 0}; vv[u][w] = uint4{0, 0, 0, 0};
+                    const int row = 2 * rp + w;
+                    if (idx < total && row < n) {
+                        const half_t *src = qkv + (size_t)(tok0 + row) * ld + h * D + c * 8;
+                        kv[u][w] = *(const uint4 *)(src + H);
+                        vv[u][w] = *(const uint4 *)(src + 2 * H);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
+                if (idx < total) {
+                    *(uint4 *)(Ks + k_off<D>(2 * rp, c)) = kv[u][0];
+                    *(uint4 *)(Ks + k_off<D>(2 * rp + 1, c)) = kv[u][1];
+                    const f16x8 a = __builtin_bit_cast(f16x8, vv[u][0]), b = __builtin_bit_cast(f16x8, vv[u][1]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+                        *(f16x2v *)(Vt + (c * 8 + e) * vt_ld + 2 * rp) = f16x2v{a[e], b[e]};
+                    }
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -115,11 +142,13 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
         for (int dv = 0; dv < D / 32; ++dv) vbase[dv] = (lds_halfs)Vt + (dv * 32 + l31) * vt_ld + 4 * hi;
         constexpr int K_ROW = D * 2;                   // bytes per K row
 
-        for (int kc = 0; kc < n_pad; kc += ATT_CHUNK) {
-            // ---- S^T chunk: 4 key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
-            f32x16 s[4];
+        constexpr int KT = CH / 32;                    // key tiles per step
+        const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
+        for (int kc = 0; kc < n_steps; kc += CH) {
+            // ---- S^T chunk: KT key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
+            f32x16 s[KT];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
+            for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
                 for (int kk = 0; kk < D / 16; ++kk) {
                     const f16x8 kf = *(const __attribute__((address_space(3))) f16x8 *)(kbase[kk] + kt * 32 * K_ROW);
@@ -128,11 +157,11 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += ATT_CHUNK * K_ROW;
+            for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
             // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
-            if (kc + ATT_CHUNK > n) {
+            if (kc + CH > n) {
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -141,17 +170,17 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             }
             float mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit; the exponent below is one
             // fma per score (the same arithmetic as qkv_attention2.hip: equal bits across the kernels)
-            const float m_new = fmaxf(m_run, mx * sc);      // finite: every chunk has >= 1 real key
+            const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
             float psum = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
             // ---- O^T += V^T * P^T
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     f16x8 pf;
@@ -185,7 +214,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     }
                 }
 #pragma unroll
-            for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += ATT_CHUNK;
+            for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += CH;
         }
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
         const int q = qb * 32 + l31;
@@ -215,11 +244,11 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
     const bool wide = n_pad > 128;
     if (lds > 64 * 1024)
         configure_once(configured[wide], [&] {                 // (once, for the largest LDS the kernel can be launched with)
-            if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-    if (wide) hipLaunchKernelGGL((attention_mfma_kernel<D, 512>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
-    else hipLaunchKernelGGL((attention_mfma_kernel<D, 256>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
+    if (wide) hipLaunchKernelGGL((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
+    else hipLaunchKernelGGL((attention_mfma_kernel<D, 256, 128>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }
 
 bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
