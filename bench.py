@@ -181,7 +181,7 @@ def committed_traffic(cfg_key, kernel):
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        d = t.get(cfg_key, {}).get(kernel)
+        d = t.get(cfg_key.replace("_host_api", ""), {}).get(kernel)      # (the host-API entry runs the same kernels on the same batch)
         return None if d is None else d["bytes"]
     except (OSError, ValueError, KeyError):
         return None
@@ -363,7 +363,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--also", type=int, nargs="*", default=None,
-                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 5)")
+                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 4, 5, 55)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inproc", action="store_true", help="one process, --gpus N devices inside libbert.so")
     args = ap.parse_args()
@@ -418,7 +418,7 @@ def main():
         else:
             kernel_roofline(res, torch, device)
         res["model"].close()
-        also = args.also if args.also is not None else ([2, 22, 3, 5, 55] if world == 1 and args.config == 1 else [])
+        also = args.also if args.also is not None else ([2, 22, 3, 4, 5, 55] if world == 1 and args.config == 1 else [])
         extras = {}
         for cid in also:
             big = CONFIGS[cid]["dims"] in ("bert-base", "mpnet-dims")

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""gpurun_out/*_<tag>.* (written by tools/r2_round_check.sh on the GPU box) -> the committed summaries under profiles/.
+"""gpurun_out/*_<tag>.* (written by tools/gpu_round_check.sh on the GPU box) -> the committed summaries under profiles/.
 usage: python tools/assemble_profiles.py [tag]"""
 import json
 import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
 P = os.path.join(root, "profiles")
@@ -42,37 +42,30 @@ for k in ("layer_tail", "qkv_attention2"):
     gui = float(find(r3, k)[next(c for c in h3 if "GRBM" in c)]) / 8          # summed over the 8 XCDs
     busy[k] = (m, gui, m / (1024 * gui))
 bench = json.loads(read(f"bench_{tag}.log"))
-hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round 2, commit {commit}; tools/r2_round_check.sh)\n"
+hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
        f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers, 2 launches per layer (qkv_attention2 + layer_tail)\n"
-       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (boxes of the pool: 274-293 k), HIP events layer_tail {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
+       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), HIP events layer_tail {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
        f"# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): layer_tail {busy['layer_tail'][0] / 1e6:.2f} M / (1024 x {busy['layer_tail'][1] / 1e3:.1f} k) = {busy['layer_tail'][2]:.2f}, "
-       f"qkv_attention2 {busy['qkv_attention2'][0] / 1e6:.2f} M / (1024 x {busy['qkv_attention2'][1] / 1e3:.1f} k) = {busy['qkv_attention2'][2]:.2f} (round 1: 0.36 / 0.28)\n")
+       f"qkv_attention2 {busy['qkv_attention2'][0] / 1e6:.2f} M / (1024 x {busy['qkv_attention2'][1] / 1e3:.1f} k) = {busy['qkv_attention2'][2]:.2f} (round 2: 0.39 / 0.33)\n")
 c3 = bench["also"]["config3"]
-with open(os.path.join(P, "r2_kernel_stats.txt"), "w") as f:
+with open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w") as f:
     f.write(hdr + read(f"stats_{tag}.txt") +
             f"\n# --config 3 (bert-base dims q4_1 expanded to f16 at load, 512 x 512 tokens per step, 12 layers): rocprofv3 --kernel-trace --stats -- python bench.py --config 3 --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --also\n"
             f"# gemm256_kernel<0> = QKV (bias), <1> = FFN up (bias + GELU), <2> = attention output and FFN down (bias + residual); same box un-profiled: {c3['value']:.0f} sentences/s = {c3['path_mfma_frac']:.3f} of the MFMA peak\n" +
             read(f"stats_config3_{tag}.txt"))
-with open(os.path.join(P, "r2_pmc.txt"), "w") as f:
+with open(os.path.join(P, f"{tag}_pmc.txt"), "w") as f:
     f.write(f"# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 2 --warmup 1 --repeat 1 --no-cpu-baseline --also   (separate runs per counter set; mean per dispatch; commit {commit})\n"
             "# SQ_* in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section)\n" +
             pmc1 + "\n" + pmc2 + "\n" + pmc3 + "\n# --config 3 (bert-base dims q4_1, 512 x 512 tokens): FETCH_SIZE / GRBM_GUI_ACTIVE / WRITE_SIZE\n" + pmc3c3)
 with open(os.path.join(P, "traffic.json"), "w") as f:
     f.write(read(f"traffic_{tag}.json"))
-with open(os.path.join(P, "r2_bench_line.json"), "w") as f:
+with open(os.path.join(P, f"{tag}_bench_line.json"), "w") as f:
     f.write(read(f"bench_{tag}.log"))
-if os.path.exists(os.path.join(g, f"bench_config4_{tag}.json")):
-    with open(os.path.join(P, "r2_config4.json"), "w") as f:
-        f.write(read(f"bench_config4_{tag}.json"))
 cal = [l for l in read(f"gemm_calibration_{tag}.txt").splitlines() if "amdgpu.ids" not in l]
-with open(os.path.join(P, "r2_gemm_calibration.txt"), "w") as f:
+with open(os.path.join(P, f"{tag}_gemm_calibration.txt"), "w") as f:
     f.write(f"# python tools/gemm_calibration.py on the box of this round check (commit {commit}): torch.matmul = hipBLASLt (Custom_Cijk_..._MT256x256x64_MI16x16x1 on the bert-base shapes), f16 in, f16 out, NO bias / GELU / residual;\n"
-            "# beside it on the same box: profiles/r2_kernel_stats.txt, config 3: gemm256_kernel<0> QKV + bias, <1> FFN up + bias + GELU, <2> attention-out / FFN down + bias + residual (average of the two)\n" +
+            f"# beside it on the same box: profiles/{tag}_kernel_stats.txt, config 3: gemm256_kernel<0> QKV + bias, <1> FFN up + bias + GELU, <2> attention-out / FFN down + bias + residual (average of the two)\n" +
             "\n".join(cal) + "\n")
-with open(os.path.join(P, "r2_store_issue.txt"), "w") as f:
-    f.write(f"# tools/ubench/store_issue, store_beside_mfma (no loads), store_beside_mfma with -DNLOAD=16 on one MI355X (commit {commit}): what 16-byte-per-lane global stores and LDS-DMA pieces cost a CU's vector-memory path\n"
-            "# (1) every wave of the chip issuing them at once: 31 cycles per 1 KiB store per CU into L2, 12.4 per LDS-DMA piece;  (2) stores between the MFMAs of one wave per SIMD: ~30-50 cycles each;\n"
-            "# (3) the same with 16 LDS-DMA pieces per 64 MFMAs in flight (a GEMM's load rate): 110-125 cycles each\n" + read(f"store_ubench_{tag}.txt"))
 print("profiles/ refreshed at", commit, {k: round(v[2], 3) for k, v in busy.items()})
 for k, v in [("config1", bench)] + list(bench["also"].items()):
     print(f"{k:22s} {v['value']:12.0f} /s  {v['ms_per_step']:8.3f} ms  frac {v.get('path_mfma_frac', 0):.3f}  host {(v.get('host_api') or {}).get('value', 0):10.0f}  cpu {(v.get('cpu_baseline') or {}).get('value', 0):8.2f}  x{v.get('speedup_vs_cpu', 0):.0f}  cos {v.get('mean_cosine_vs_cpu')}")
