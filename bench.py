@@ -228,7 +228,7 @@ def host_api_rate(res, calls=None):
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
     return {"value": B / med, "unit": "sentences/s", "ms_per_call": 1e3 * med, "min": B / max(ts), "max": B / min(ts), "calls": calls,
-            "entry": "bert_hip_eval_packed (host ids -> host embeddings: pinned staging, H2D, forward, D2H, blocking)"}, out
+            "entry": "bert_hip_eval_packed (host ids -> host embeddings: pinned staging, one H2D copy, forward, rows written into pinned host memory, blocking)"}, out
 
 
 def latency_b1(tmpdir, calls=200):

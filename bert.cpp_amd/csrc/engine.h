@@ -102,12 +102,13 @@ private:
     // host path: two sets of pinned staging + device id / embedding buffers, so that the host stages chunk i+1 and
     // unpacks chunk i-1 while the GPU computes chunk i (eval_packed_host)
     struct HostSlot {
-        int32_t *h_tokens = nullptr, *h_cu = nullptr;
-        float *h_out = nullptr;
-        size_t h_tokens_cap = 0, h_cu_cap = 0, h_out_cap = 0;
-        DevBuf d_tokens, d_cu, d_out, d_windows;
-        int2 *h_windows = nullptr;
-        size_t h_windows_cap = 0;
+        // ONE pinned staging block per chunk — ids | cu_seqlens | windows, each part 16-byte aligned — and one device image of
+        // it: a single H2D copy per chunk.  The embeddings come back without a copy: the pooling kernel writes them straight
+        // into h_out (pinned, mapped into the device's address space as d_out_host).
+        char *h_in = nullptr;
+        float *h_out = nullptr, *d_out_host = nullptr;
+        size_t h_in_cap = 0, h_out_cap = 0;
+        DevBuf d_in, d_out;
         hipEvent_t done = nullptr;
     } slot_[2];
 

@@ -272,10 +272,8 @@ Engine::~Engine() {
     for (auto ev : ev_pool_) (void)hipEventDestroy(ev);
     for (auto &p : pending_) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto &sl : slot_) {
-        if (sl.h_tokens) (void)hipHostFree(sl.h_tokens);
-        if (sl.h_cu) (void)hipHostFree(sl.h_cu);
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
         if (sl.h_out) (void)hipHostFree(sl.h_out);
-        if (sl.h_windows) (void)hipHostFree(sl.h_windows);
         if (sl.done) (void)hipEventDestroy(sl.done);
     }
     if (busy_) (void)hipEventDestroy(busy_);
@@ -529,14 +527,16 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     // every buffer is sized for the largest chunk BEFORE anything is queued: growing one later would free memory that
     // a queued chunk still uses
     const int n_slots = chunks.size() > 1 ? 2 : 1;
+    auto pad16 = [](size_t n) { return (n + 15) & ~(size_t)15; };
+    const size_t in_bytes = pad16(max_T * 4) + pad16((max_nb + 1) * 4) + pad16(max_nb * sizeof(int2));
     for (int i = 0; i < n_slots; ++i) {
         HostSlot &sl = slot_[i];
-        if (!ensure_pinned((void **)&sl.h_tokens, &sl.h_tokens_cap, max_T * 4, err)) return -1;
-        if (!ensure_pinned((void **)&sl.h_cu, &sl.h_cu_cap, (max_nb + 1) * 4, err)) return -1;
+        if (!ensure_pinned((void **)&sl.h_in, &sl.h_in_cap, in_bytes, err)) return -1;
+        const size_t out_cap = sl.h_out_cap;
         if (!ensure_pinned((void **)&sl.h_out, &sl.h_out_cap, max_nb * H * 4, err)) return -1;
-        if (!ensure_pinned((void **)&sl.h_windows, &sl.h_windows_cap, max_nb * sizeof(int2), err)) return -1;
-        if (!sl.d_tokens.ensure(max_T * 4, err) || !sl.d_cu.ensure((max_nb + 1) * 4, err) || !sl.d_out.ensure(max_nb * H * 4, err) ||
-            !sl.d_windows.ensure(max_nb * sizeof(int2), err)) return -1;
+        if (sl.h_out_cap != out_cap || !sl.d_out_host)
+            HIP_OK(hipHostGetDevicePointer((void **)&sl.d_out_host, sl.h_out, 0), err, -1);
+        if (!sl.d_in.ensure(in_bytes, err) || (d_embeddings && !sl.d_out.ensure(max_nb * H * 4, err))) return -1;
         if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
     }
     if (!ensure_workspace((int)((max_T + 255) / 256 * 256), (int)max_nb, err)) return -1;
@@ -554,25 +554,27 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     for (size_t i = 0; i < chunks.size(); ++i) {
         HostSlot &sl = slot_[i & 1];
         const int b0 = chunks[i].b0, nb = chunks[i].b1 - b0, T = cu[chunks[i].b1] - cu[b0];
-        memcpy(sl.h_tokens, tokens + cu[b0], (size_t)T * 4);
-        for (int j = 0; j <= nb; ++j) sl.h_cu[j] = cu[b0 + j] - cu[b0];
+        const size_t off_cu = pad16((size_t)T * 4), off_w = off_cu + pad16((size_t)(nb + 1) * 4);
+        int32_t *h_cu = (int32_t *)(sl.h_in + off_cu);
+        memcpy(sl.h_in, tokens + cu[b0], (size_t)T * 4);
+        for (int j = 0; j <= nb; ++j) h_cu[j] = cu[b0 + j] - cu[b0];
         int n_windows = 0;
         if (chunks[i].max_len <= 128) {
-            build_windows(sl.h_cu, nb, windows);
+            build_windows(h_cu, nb, windows);
             n_windows = (int)windows.size();
-            memcpy(sl.h_windows, windows.data(), windows.size() * sizeof(int2));
+            memcpy(sl.h_in + off_w, windows.data(), windows.size() * sizeof(int2));
         }
-        if (hipMemcpyAsync(sl.d_tokens.p, sl.h_tokens, (size_t)T * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
-            hipMemcpyAsync(sl.d_cu.p, sl.h_cu, (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, stream_) != hipSuccess ||
-            (n_windows && hipMemcpyAsync(sl.d_windows.p, sl.h_windows, (size_t)n_windows * sizeof(int2), hipMemcpyHostToDevice, stream_) != hipSuccess)) {
+        if (hipMemcpyAsync(sl.d_in.p, sl.h_in, off_w + (size_t)n_windows * sizeof(int2), hipMemcpyHostToDevice, stream_) != hipSuccess) {
             err = "hipMemcpyAsync (ids) failed";
             return fail();
         }
-        if (eval_packed_device(sl.d_tokens.as<int32_t>(), sl.d_cu.as<int32_t>(), nb, T, chunks[i].max_len, sl.d_out.as<float>(),
-                               stream_, nullptr, err, n_windows ? sl.d_windows.as<int2>() : nullptr, n_windows) != 0)
+        const char *d_in = (const char *)sl.d_in.p;
+        // host destination: the pooling kernel's rows go straight into the pinned block (no D2H copy behind the pass)
+        float *out = d_embeddings ? sl.d_out.as<float>() : sl.d_out_host;
+        if (eval_packed_device((const int32_t *)d_in, (const int32_t *)(d_in + off_cu), nb, T, chunks[i].max_len, out, stream_, nullptr, err,
+                               n_windows ? (const int2 *)(d_in + off_w) : nullptr, n_windows) != 0)
             return fail();
-        if ((d_embeddings ? hipMemcpyAsync(d_embeddings + (size_t)b0 * H, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToDevice, stream_)
-                          : hipMemcpyAsync(sl.h_out, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToHost, stream_)) != hipSuccess ||
+        if ((d_embeddings && hipMemcpyAsync(d_embeddings + (size_t)b0 * H, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToDevice, stream_) != hipSuccess) ||
             hipEventRecord(sl.done, stream_) != hipSuccess) {
             err = "hipMemcpyAsync (embeddings) failed";
             return fail();
