@@ -16,9 +16,11 @@
 //   * ONE PERSISTENT WORKGROUP PER CU walks its share of the output tiles (each XCD a contiguous range, all feature tiles
 //     of a token tile back to back: an activation tile comes from HBM once, not once per XCD) and the stream of reduction
 //     tiles runs across output tiles without a gap — no workgroup launch, prologue latency or drained pipeline per tile;
-//   * epilogue: bias, GELU and the residual are applied in f32 in the accumulator layout and rounded once (as gemm.hip
-//     does), then a wave passes its own 64 tokens x 128 features through a private 4 KiB staging area in four rounds, so
-//     every global store is 16 bytes of a full 128-byte row segment; no barrier, no use of the tile buffers.
+//   * the accumulators of a tile START from bias (+ residual): those loads are issued between the two phases of the finished
+//     tile's epilogue (the bias vectors straight into the dead accumulator tuples) and land under its stores, so a tile
+//     boundary has no load round trip of its own; epilogue: GELU in f32 -> packed f16 in the accumulator layout, one rounding,
+//     then a wave passes its own 64 tokens x 128 features through a private 4 KiB staging area in four rounds, so every global
+//     store is 16 bytes of a full 128-byte row segment; no barrier, no use of the tile buffers.
 // Measured (bert-base, 512 x 512 tokens, per reduction tile 1.45 us = 88 % of the matrix rate the board sustains at its
 // power limit; hipBLASLt's 256x256x64 kernel on the same shapes: QKV 836 us, this kernel 960): what is left is the epilogue
 // — 128 store instructions per tile at 31-52 cycles each per CU (tools/ubench/store_issue.hip) with no MFMA beside them.
@@ -188,12 +190,65 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[i], f.b[j], acc[i][j], 0, 0, 0);
     };
 
-    // ---- epilogue of the output tile at (em0, en0): bias (+ GELU | + residual) in f32 in the accumulator layout (lane =
-    // token, registers = 4-feature runs), one rounding, then through a wave-private 4 KiB staging area in four rounds of
-    // [32 tokens][64 features] so that every global store is 16 bytes of a full 128-byte row segment.  No barrier: a wave
-    // stages and stores its own 64 tokens x 128 features.
+    // ---- the accumulators of an output tile START from bias (+ residual): what the round-2 form added in its epilogue —
+    // sixteen bias vectors and, for the residual form, 32 scattered 8-byte loads per lane, fetched in six dependent round trips
+    // per tile with nothing else to do (14-25 us of a 35 us tile) — is requested for the NEXT tile between the two phases of
+    // the finished tile's epilogue and lands under its stores.  (The sum starts from the bias instead of ending with it:
+    // f32, same tolerance; the tests compare against float64.)
+    // The bias vectors are loaded straight INTO the accumulator tuples of token block 0 (dead between the two phases), token
+    // block 1 copies them when they have landed: through registers of their own they would be alive beside all 128
+    // accumulators and both fragment sets at the tile's first MFMAs (the compiler feeds them in as C operands) — sixteen
+    // spilled behind a vmcnt(0).
+    // The residual comes in in the accumulator layout (a lane's 8-byte runs of its token's row: 32 loads per lane and tile, 32
+    // lines per instruction — 8-9 us of a 35 us tile go into their issue wherever they are placed; fetching the tile in
+    // 16-byte row segments and turning it through the staging area was tried: the register allocator spills all sixteen
+    // vectors in front of the stores, and landing them by LDS-DMA has to wait behind the stores round by round).
+    f16x4 rv[EPI == EPI_BIAS_RESID ? 4 : 1][2][4];
+    auto init_loads = [&](int im0, int in0) __attribute__((always_inline)) {
+        int l31 = lane & 31, hi = lane >> 5;
+        asm volatile("" : "+v"(l31), "+v"(hi));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 b = *(const f32x4 *)(p.bias + in0 + wf * 128 + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = b[e];
+            }
+        if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const half_t *rrow = p.resid + ((size_t)im0 + wq * 64 + j * 32 + l31) * p.N + in0 + wf * 128 + 4 * hi;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rv[i][j][g] = *(const f16x4 *)(rrow + i * 32 + 8 * g);
+            }
+        }
+    };
+    auto init_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b = acc[i][0][4 * g + e];
+                    if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
+                        acc[i][1][4 * g + e] = b + (float)rv[i][1][g][e];
+                        acc[i][0][4 * g + e] = b + (float)rv[i][0][g][e];
+                    } else {
+                        acc[i][1][4 * g + e] = b;
+                    }
+                }
+    };
+
+    // ---- epilogue of the output tile at (em0, en0): GELU where asked for, one rounding (bias and residual are inside the
+    // accumulators already), then through a wave-private 4 KiB staging area in four rounds of [32 tokens][64 features] so
+    // that every global store is 16 bytes of a full 128-byte row segment.  No barrier: a wave stages and stores its own
+    // 64 tokens x 128 features.  `next`: the tile whose initial values are requested between the phases.
     char *const stg = smem + 2 * G2_STAGE + wave * 4096;
-    auto epilogue = [&](int em0, int en0) __attribute__((always_inline)) {
+    auto epilogue = [&](int em0, int en0, bool next, int nm0, int nn0) __attribute__((always_inline)) {
         // (opaque copies: every address below is computed here, not hoisted out of the tile loop into registers that
         // the accumulators need)
         int l31 = lane & 31, hi = lane >> 5, lane_e = lane;
@@ -203,52 +258,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) asm volatile("" : : "v"(acc[i][j]));
+            init_loads(next ? nm0 : em0, next ? nn0 : en0);
             return;
         }
-        // phase 1, registers only: EVERY load of the epilogue (bias, residual) is issued and consumed before the first
-        // store — vmcnt retires in issue order, so a load behind a store would wait for that store's acknowledgement
-        // (measured: the residual form cost 16-25 us per tile with loads and stores alternating round by round)
-        f16x4 o[2][2][2][4];                               // [ip][j][ii][g]: 64 registers, the accumulators' own as they die
+        // phase 1, registers only.  The rounded tile is gathered into FOUR 16-register tuples (round (ip, j) = the two
+        // accumulator blocks 2 ip, 2 ip + 1 of token block j, converted in place into the first one's registers): left to the
+        // allocator the packed halves stay scattered over all eight accumulator tuples, one register in two, and the 64
+        // registers that are free hold no 4-register run for the next tile's bias vectors — sixteen of them were spilled.
+        typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+        u32x16 o16[4];
 #pragma unroll
-        for (int ip = 0; ip < 2; ++ip) {
-            f32x4 bq[2][4];
+        for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bq[ii][g] = *(const f32x4 *)(p.bias + en0 + wf * 128 + (2 * ip + ii) * 32 + 8 * g + 4 * hi);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                f16x4 rv[2][4];
-                if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
-                    const half_t *rrow = p.resid + ((size_t)em0 + wq * 64 + j * 32 + l31) * p.N + en0 + wf * 128 + 4 * hi;
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) rv[ii][g] = *(const f16x4 *)(rrow + (2 * ip + ii) * 32 + 8 * g);
-                }
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[2 * ip + ii][j][4 * g + e] + bq[ii][g][e];
-                        if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)rv[ii][g][e];
-                        }
+                        const f32x16 &a = acc[2 * ip + ii][j];
+                        f16x4 h;
                         if (EPI == EPI_BIAS_GELU) {
                             // packed f16, as layer_tail.hip evaluates it (the reference reads the GELU from an f16 table)
-                            const f16x2_t g0 = gelu_pk16(v[0], v[1]), g1 = gelu_pk16(v[2], v[3]);
-                            o[ip][j][ii][g][0] = g0[0]; o[ip][j][ii][g][1] = g0[1]; o[ip][j][ii][g][2] = g1[0]; o[ip][j][ii][g][3] = g1[1];
+                            const f16x2_t g0 = gelu_pk16(a[4 * g], a[4 * g + 1]), g1 = gelu_pk16(a[4 * g + 2], a[4 * g + 3]);
+                            h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
                             __builtin_amdgcn_sched_barrier(0);   // one run at a time: the GELU temporaries of several would spill
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) o[ip][j][ii][g][e] = (_Float16)v[e];
+                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)a[4 * g + e];
                         }
+                        const uint2 hb = __builtin_bit_cast(uint2, h);
+                        o16[ip * 2 + j][(ii * 4 + g) * 2] = hb.x;
+                        o16[ip * 2 + j][(ii * 4 + g) * 2 + 1] = hb.y;
                     }
-            }
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's initial values: every load of the tile boundary is issued here, in front of the first store (vmcnt
+        // retires in issue order: a load behind a store would wait for that store's acknowledgement) and BEHIND phase 1 (the
+        // tile coordinates are handed over through an asm that reads phase 1's last results: hoisted above it, as the
+        // compiler did with four of the loads, they land while all 128 accumulators are still alive and get spilled).  After
+        // the last tile the loads are repeated for the tile itself: cheaper than a branch around them.
+        {
+            int im0 = next ? nm0 : em0, in0 = next ? nn0 : en0;
+            asm volatile("" : "+s"(im0), "+s"(in0) : "v"(o16[0][15]), "v"(o16[1][15]), "v"(o16[2][15]), "v"(o16[3][15]), "v"(o16[0][0]), "v"(o16[1][0]), "v"(o16[2][0]), "v"(o16[3][0]) : "memory");
+            init_loads(im0, in0);
         }
+        __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_sched_barrier(0);
         // phase 2, no loads: four rounds of [32 tokens][64 features] through the staging area
 #pragma unroll
@@ -259,8 +312,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                 for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        if (G2_ABLATE & 8) asm volatile("" : : "v"(o[ip][j][ii][g]));
-                        else *(f16x4 *)(stg + l31 * 128 + (((ii * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = o[ip][j][ii][g];
+                        const uint2 hb = {o16[ip * 2 + j][(ii * 4 + g) * 2], o16[ip * 2 + j][(ii * 4 + g) * 2 + 1]};
+                        if (G2_ABLATE & 8) asm volatile("" : : "v"(hb.x), "v"(hb.y));
+                        else *(uint2 *)(stg + l31 * 128 + (((ii * 4 + g) ^ (l31 & 7)) << 4) + hi * 8) = hb;
                     }
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -292,6 +346,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
         dma_piece(w, smem, I4{}); dma_piece(w, smem, I5{}); dma_piece(w, smem, I6{}); dma_piece(w, smem, I7{});
     }
+    init_loads(m0, n0);                                // (the first tile's initial values: one exposed round trip per launch)
+    init_acc();
     G2Frag f0, f1;
     bool have_prev = false;
     int pm0 = 0, pn0 = 0;
@@ -332,14 +388,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             });
             if (have_prev) {
                 mfma_step(f1);                         // the last k-step of the previous output tile
-                epilogue(pm0, pn0);
+                epilogue(pm0, pn0, true, m0, n0);
+                init_acc();
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
             read_frag(f0, I0{});
             steps_0_to_2(na, nw, nstage);
             stage ^= 1;
@@ -364,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // the request issued behind the last output tile must not outlive the workgroup
     g2_tile_barrier(f1);
     mfma_step(f1);
-    epilogue(pm0, pn0);
+    epilogue(pm0, pn0, false, 0, 0);
 }
 
 bool gemm256_supported(const GemmWeight &W, int M_pad) {
