@@ -452,8 +452,9 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                // g * ((v - mean) * rstd) + b  =  v * (g * rstd) + (g * (-mean * rstd) + b)
-                const _Float16 y = (_Float16)__builtin_fmaf(accp[b][4 * gq + e], gv[gq][e] * ln_rstd, __builtin_fmaf(gv[gq][e], ln_nmr, bv[gq][e]));
+                // g * ((v - mean) * rstd) + b  =  v * (g * rstd) + (g * (-mean * rstd) + b), rounded to f32 and THEN to f16 (never the
+                // single-rounding v_fma_mixlo_f16: skinny.hip's LayerNorm must give the same bits, whatever the compiler prefers there)
+                const _Float16 y = (_Float16)rounded_f32(__builtin_fmaf(accp[b][4 * gq + e], gv[gq][e] * ln_rstd, __builtin_fmaf(gv[gq][e], ln_nmr, bv[gq][e])));
                 if (gq < 2) y0[4 * gq + e] = y; else y1[4 * (gq - 2) + e] = y;
             }
         asm volatile("" ::: "memory");                        // (one block's parameters at a time: unfenced, the loads of all blocks are hoisted to the front)
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
                     for (int hq = 0; hq < 2; ++hq)
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            o[4 * hq + e] = (_Float16)__builtin_fmaf(acc2[n][8 * s + 4 * hq + e], gv[2 * s + hq][e] * rstd, __builtin_fmaf(gv[2 * s + hq][e], nmr, bv[2 * s + hq][e]));
+                            o[4 * hq + e] = (_Float16)rounded_f32(__builtin_fmaf(acc2[n][8 * s + 4 * hq + e], gv[2 * s + hq][e] * rstd, __builtin_fmaf(gv[2 * s + hq][e], nmr, bv[2 * s + hq][e])));
                     *(f16x8 *)(S + q * 1024 + ((lane + 2 * q) & 63) * 16) = o;
                 }
                 asm volatile("" ::: "memory");

@@ -39,53 +39,6 @@ struct SkinnyArgs {
     int N, K;
 };
 
-// LayerNorm of one token's row, the way layer_tail.hip's lanes and wave pairs do it: lane = (token l31, half hi) holds the
-// 4-feature runs (n, g) = features 32 n + 8 g + 4 hi .. + 3 of its token (H / 2 values, loaded 16 bytes at a time).
-// PAIR (LayerNorm 1): the statistics are the sum of two half-row sums (features with (f & 127) < 64: layer_tail's U wave;
-// the rest: its D wave), each summed block by block, register by register, then across the lane halves; !PAIR (LayerNorm
-// 2): one sum over all blocks (the D wave owns whole rows).  Result: the normalised runs, f16.
-template <bool PAIR, int NT>
-__device__ __forceinline__ void layernorm_runs(const float *row, const float *gamma, const float *beta, int hi, f16x4 (&y)[4 * NT][4]) {
-    constexpr int H = 128 * NT;
-    f32x4 x[4 * NT][4];
-#pragma unroll
-    for (int n = 0; n < 4 * NT; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) x[n][g] = *(const f32x4 *)(row + 32 * n + 8 * g + 4 * hi);
-    float s1 = 0.f, s2 = 0.f;
-    auto add_block = [&](float &a1, float &a2, int n) __attribute__((always_inline)) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a1 += x[n][g][e]; a2 = __builtin_fmaf(x[n][g][e], x[n][g][e], a2); }
-    };
-    if constexpr (PAIR) {
-        float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
-#pragma unroll
-        for (int role = 0; role < 2; ++role)
-#pragma unroll
-            for (int b = 0; b < 2 * NT; ++b) add_block(t1[role], t2[role], (b >> 1) * 4 + role * 2 + (b & 1));
-#pragma unroll
-        for (int role = 0; role < 2; ++role) { t1[role] += __shfl_xor(t1[role], 32); t2[role] += __shfl_xor(t2[role], 32); }
-        s1 = t1[0] + t1[1]; s2 = t2[0] + t2[1];
-    } else {
-#pragma unroll
-        for (int n = 0; n < 4 * NT; ++n) add_block(s1, s2, n);
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-    }
-    float rstd, nmr;
-    layernorm_scale(s1, s2, 1.0f / H, rstd, nmr);
-#pragma unroll
-    for (int n = 0; n < 4 * NT; ++n)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int f = 32 * n + 8 * g + 4 * hi;
-            const f32x4 gv = *(const f32x4 *)(gamma + f), bv = *(const f32x4 *)(beta + f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[n][g][e] = (_Float16)__builtin_fmaf(x[n][g][e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
-        }
-}
-
 }  // namespace
 
 // grid = (N / 32 feature tiles, token blocks), block = 64: ONE wave per workgroup owns 32 tokens x 32 features (up to 192
