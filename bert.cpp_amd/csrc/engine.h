@@ -113,7 +113,7 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, one_launch_ = true, q4_expand_ = true;
     int chunk_tokens_ = 262144;
 
     // profiling

@@ -213,7 +213,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     // | naive (the generic kernels: any shape, row-major f16 images); finer switches: bert_hip_set_option
     if (const char *k = getenv("BERT_HIP_KERNELS")) {
         if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
-        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false;
+        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = e->one_launch_ = false;
     }
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
@@ -310,6 +310,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
+    else if (key == "one_launch") one_launch_ = value != "0";
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -459,7 +460,23 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             tap(il + 1);
         }
     }
-    for (int il = 0; !skinny && il < hp_.n_layer; ++il) {
+    // Batches of FULL windows (every sentence exactly 128 tokens: T = 128 B): all layers in one launch, a workgroup per window
+    // (model_kernel.hip) — the two fused kernels' bodies as phases, no kernel boundary to put the workgroups back in step.
+    // (T = 128 B with no sentence over 128 tokens: every window is one whole sentence, whatever list the caller built)
+    const bool one_launch = !skinny && one_launch_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && !d_hidden &&
+                            model_kernel_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w, hp_.n_layer, nh, dh, B, T, max_len);
+    if (one_launch) {
+        ModelLayerWeights mw[16];
+        for (int il = 0; il < hp_.n_layer; ++il) {
+            LayerWeights &L = *layers_[il];
+            mw[il] = {&L.qkv.w, &L.o.w, &L.ffi.w, &L.ffo.w, L.qkv_b.as<float>(), L.o_b.as<float>(), L.ln_att_w.as<float>(), L.ln_att_b.as<float>(),
+                      L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(), L.ln_out_b.as<float>()};
+        }
+        timed("model_kernel", hp_.n_layer * (2.0 * Td * 3 * H * H + att_flops + 2.0 * Td * H * H + 4.0 * Td * H * I), s, [&] {
+            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, nh, s);
+        });
+    }
+    for (int il = 0; !skinny && !one_launch && il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
         if (qkv2_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths

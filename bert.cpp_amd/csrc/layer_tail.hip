@@ -153,21 +153,22 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8 &a, const f16x8 &b, const f
 
 }  // namespace
 
+// (the kernel's body as a device function of (arguments, the workgroup's LDS, 128-token block index): model_kernel.hip runs it as
+// one phase of a launch that carries a window through all layers)
 template <int NT, int WT>
-__global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
+__device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, const int block, const int tid) {
     constexpr bool Q4 = WT != GW_F16;
     constexpr int VMQ = Q4 ? 63 : 0;                          // (q4: no LDS-DMA in flight, nothing for a barrier to wait for)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 128 * NT, NBH = 2 * NT, NB = 4 * NT, NQ = 8 * NT, NYH = 4 * NT;
     constexpr int P = NT * NT;                                // out-projection intervals (two [128 x 64] tiles each)
     constexpr int NG = NT;                                    // intervals over which the GELU of a chunk is spread
     constexpr int LAGT = NT + NG;                             // D runs this many intervals behind U
     const int I = a.I, NC = I / 64;                           // chunks of 64 intermediate features (even, >= 2)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = wave & 3, role = wave >> 2;                 // token block; 0 = U (up-projection + GELU), 1 = D (down-projection)
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tok_w = blockIdx.x * 128 + t * 32;              // first token of this pair
+    const int tok_w = block * 128 + t * 32;                   // first token of this pair
 
     char *ringU = smem;                                       // 3 x 16 KiB
     char *ringD = smem + 3 * LT_TILE;                         // 3 x 16 KiB
@@ -469,7 +470,8 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     auto store_rows = [&]() __attribute__((always_inline)) {
         LT_STAMP(tlU, 394);
         const char *S = smem + t * (64 * H);
-        const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane));                     // (made here, every time: as a phase of model_kernel.hip the address arithmetic below is loop-invariant)
         // 16-byte unit (token, 8-feature chunk c8) of the output = bytes h2*8.. of the fragments (q, token) and
         // (q, token + 32), q = c8 >> 1, h2 = c8 & 1
         half_t *ow = a.out + (size_t)tok_w * H;
@@ -831,7 +833,9 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
         // ================================ LayerNorm 2 (wave-local) -> rows staged in LDS ================================
         {
             char *S = smem + t * (64 * H);                    // 32 tokens x H halfs (the rings are idle: every wave is past its last read)
-            const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), hi = lane >> 5;   // (not kept through the loop)
+            int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (not kept through the loop)
+            asm volatile("" : "+v"(lane));
+            const int hi = lane >> 5;
             // U's half of the residual: fragment m = 4 n3 + 2 obp + s of pair t = registers 8 s .. of block 4 n3 + obp
             {
                 const char *const xu = ringU + t * (NYH * 1024) + lane * 16;
@@ -884,9 +888,17 @@ __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     }
 }
 
+template <int NT, int WT>
+__global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    layer_tail_body<NT, WT>(a, smem, (int)blockIdx.x, (int)threadIdx.x);
+}
+
 static size_t layer_tail_lds(int H, int I) {
     return (size_t)6 * LT_TILE + 32768 + 8 * 64 * 4 + (size_t)(6 * H + I + 128) * sizeof(float);
 }
+
+#ifndef BERT_HIP_PHASES_ONLY
 
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2) {
     const int H = W1.K, I = W1.N;
@@ -943,5 +955,7 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
     default:      if (nt3) go(layer_tail_kernel<3, GW_Q4_1>, 5); else go(layer_tail_kernel<2, GW_Q4_1>, 4); break;
     }
 }
+
+#endif  // BERT_HIP_PHASES_ONLY
 
 }  // namespace bert_hip

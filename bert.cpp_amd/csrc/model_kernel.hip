@@ -1,0 +1,111 @@
+// model_kernel.hip — ONE launch for all encoder layers of a batch of FULL windows (every sentence exactly 128 tokens, f16
+// weights, H = 256 / 384, d_head 32): reference bert.cpp:816-901, the whole loop over layers.
+//
+// Why: with one kernel per layer half (qkv_attention2, layer_tail) a 256-sentence step is ONE workgroup per CU per launch,
+// all 256 in lockstep — everybody's load burst (ctx + x: 48 MB at the HBM limit), everybody's compute, everybody's store
+// burst, twelve times per forward pass; two free-running half-batch lanes already measure +4-6 % (tools/dual_lane_probe.py),
+// but a call has to join its lanes.  A window's tokens depend on no other window's: here a workgroup carries ITS window
+// through every layer — window-kernel phase (Q|K|V projection + attention), layer-tail phase (out-projection + LN + FFN + LN),
+// the two kernels' bodies unchanged (same arithmetic, same bits: tested) — and nothing ever puts the workgroups back in step.
+// The hand-overs (ctx from the attention waves to the tail, x from the tail to the next layer's projection waves) are plain
+// global stores and loads of the SAME workgroup: 96 KiB each, written and read back through the CU's L1 / the XCD's L2 behind a
+// workgroup-scope fence (one L1 per CU, shared by the workgroup's waves: no invalidate needed outside threadgroup-split
+// mode), so the per-layer load bursts leave the HBM.
+//
+// Both bodies keep their own LDS layout (160 KiB each, used one after the other) and register budget (256 per wave).  This
+// translation unit is compiled with the flags of both (Makefile): -fno-slp-vectorize (qkv_attention2) and
+// -structurizecfg-skip-uniform-regions (layer_tail).
+#define BERT_HIP_PHASES_ONLY
+#include "qkv_attention2.hip"
+#include "layer_tail.hip"
+#undef BERT_HIP_PHASES_ONLY
+
+namespace bert_hip {
+
+namespace {
+
+constexpr int MODEL_MAX_LAYERS = 12;
+
+struct ModelLayerArgs {              // what differs from layer to layer
+    const half_t *wqkv, *wo, *w1p, *w2p;
+    const float *bqkv, *bo, *g1, *be1, *b1, *b2, *g2, *be2;
+};
+struct ModelArgs {
+    half_t *x, *ctx;                 // [T][H] hidden state (in: embeddings + LN; out: the last layer's output), attention context
+    const int32_t *cu;
+    int n_layer, n_head, n_sent, I;
+    ModelLayerArgs layer[MODEL_MAX_LAYERS];
+};
+
+}  // namespace
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int window = (int)blockIdx.x;              // = sentence = 128-token block
+    // The thread id is REBUILT per phase from the wave's index (a scalar register) and the lane count: with threadIdx.x itself
+    // the compiler hoists both phases' lane-dependent address arithmetic out of the layer loop — eighty registers' worth —
+    // and spills it; even one vector register alive across the phases is one more than the layer tail has (a scratch reload
+    // among its hand-counted LDS-DMA pieces would break their vmcnt arithmetic).
+    const int wave_index = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    auto thread_id = [&]() __attribute__((always_inline)) {
+        int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), w = wave_index;
+        asm volatile("" : "+v"(ln), "+s"(w));
+        return w * 64 + ln;
+    };
+    for (int l = 0; l < m.n_layer; ++l) {
+        const ModelLayerArgs &L = m.layer[l];
+        int tid = thread_id();
+        {
+            Qkv2Args q;
+            q.x = m.x; q.w = L.wqkv; q.qs = nullptr; q.sc = nullptr; q.bias = L.bqkv; q.cu = m.cu; q.groups = nullptr; q.n_groups = nullptr;
+            q.out = m.ctx; q.n_head = m.n_head; q.n_sent = m.n_sent; q.spw = 1;
+            qkv_attention2_body<2 * NT, NT, GW_F16>(q, smem, window, tid);
+        }
+        // ctx is written (attention waves), every LDS access of the phase has returned: hand over to the tail
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        tid = thread_id();
+        {
+            TailArgs t;
+            t.ctx = m.ctx; t.x = m.x; t.wo = L.wo; t.w1p = L.w1p; t.w2p = L.w2p;
+            t.wo_qs = t.w1_qs = t.w2_qs = nullptr; t.wo_sc = t.w1_sc = t.w2_sc = nullptr;
+            t.bo = L.bo; t.g1 = L.g1; t.be1 = L.be1; t.b1 = L.b1; t.b2 = L.b2; t.g2 = L.g2; t.be2 = L.be2; t.out = m.x; t.I = m.I;
+            layer_tail_body<NT, GW_F16>(t, smem, window, tid);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, int n_layer,
+                            int n_head, int d_head, int n_sentences, int n_tokens, int max_len) {
+    const int H = n_head * d_head;
+    return n_layer <= MODEL_MAX_LAYERS && (H == 256 || H == 384) && max_len == 128 && (long long)n_sentences * 128 == n_tokens &&
+           Wqkv.type == GW_F16 && Wo.type == GW_F16 && qkv_attention2_supported(Wqkv, n_head, d_head, max_len) && layer_tail_supported(Wo, W1, W2);
+}
+
+void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
+                         int n_head, hipStream_t stream) {
+    ModelArgs m;
+    m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N;
+    for (int l = 0; l < n_layer; ++l) {
+        const ModelLayerWeights &s = layers[l];
+        ModelLayerArgs &d = m.layer[l];
+        d.wqkv = s.Wqkv->w16; d.wo = s.Wo->w16; d.w1p = s.W1->w16p; d.w2p = s.W2->w16p;
+        d.bqkv = s.bqkv; d.bo = s.bo; d.g1 = s.g1; d.be1 = s.be1; d.b1 = s.b1; d.b2 = s.b2; d.g2 = s.g2; d.be2 = s.be2;
+    }
+    const int H = layers[0].W1->K, KT = H / 64, GB = KT / 2;
+    const size_t lds_q = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * H * sizeof(float);
+    const size_t lds = std::max(lds_q, layer_tail_lds(H, m.I));
+    static DeviceFlags configured[4];
+    auto go = [&](auto kernel, int which) {
+        configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        hipLaunchKernelGGL(kernel, dim3(n_sentences), dim3(512), lds, stream, m);
+    };
+    if (H == 256) go(model_kernel<2>, 2); else go(model_kernel<3>, 3);
+}
+
+}  // namespace bert_hip

@@ -111,10 +111,11 @@ __device__ __forceinline__ void q2_head_barrier() {
 // H = 64 * KT = 32 * n_head; a slab = GB k-tiles, NBAR = KT / GB slabs per head.  WT: GW_F16, or GW_Q4_0 / GW_Q4_1 — the
 // weights stay 4-bit in HBM and L2; the projection waves fetch the raw blocks of a slab into registers one slab period ahead
 // of expanding them into the ring slot the f16 form fills by LDS-DMA (same tile image, same MFMA sequence, same bits).
+// (the kernel's body as a device function of (arguments, the workgroup's LDS, window index): model_kernel.hip runs it as one
+// phase of a launch that carries a window through all layers)
 template <int KT, int GB, int WT>
-__global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
+__device__ __forceinline__ void qkv_attention2_body(const Qkv2Args &a, char *smem, const int window, const int tid) {
     constexpr bool Q4 = WT != GW_F16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int H = 64 * KT, NBAR = KT / GB, SLAB = GB * Q2_TILE, PPS = 3 * GB;   // PPS = DMA pieces per slab and wave
     static_assert(KT == 2 * GB && NBAR == 2, "");
     constexpr int QKV_BYTES = 2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2;   // Q [128][32] + K [128][32] (q2_off32 swizzle) + V^T [32][Q2_VT_LD]
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     char *QKV = smem + 3 * SLAB;                              // two copies: head h in copy h & 1
     float *BS = (float *)(QKV + 2 * QKV_BYTES);               // [2H] Q and K bias (the V bias comes from global memory)
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int blk = wave & 3;                                 // token block (projection) / query block (attention)
@@ -150,14 +151,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     // ---- the window: sentences first .. first+count-1, sentence j at slots [off_j, off_j + n_j)
     int first, count;
     if (a.groups) {
-        if (a.n_groups && (int)blockIdx.x >= *a.n_groups) {   // beyond the windows the device-side builder produced
+        if (a.n_groups && window >= *a.n_groups) {   // beyond the windows the device-side builder produced
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
-        const int2 g = a.groups[blockIdx.x];
+        const int2 g = a.groups[window];
         first = g.x; count = g.y;
     }
-    else { first = blockIdx.x * a.spw; count = min(a.spw, a.n_sent - first); }
+    else { first = window * a.spw; count = min(a.spw, a.n_sent - first); }
     if (count <= 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (never taken by the launcher's grids) the DMA must not outlive the workgroup
         return;
@@ -543,6 +544,13 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
     }
 }
 
+template <int KT, int GB, int WT>
+__global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    qkv_attention2_body<KT, GB, WT>(a, smem, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+#ifndef BERT_HIP_PHASES_ONLY
 // ---------------------------------------------------------------------------------------------------------------------
 // Next-fit windows built ON THE DEVICE (the asynchronous device API has the sentence lengths in HBM only): the same rule as
 // Engine::build_windows — sentences in order, each starting at a multiple of 16 slots, the open window is closed when the next
@@ -649,5 +657,7 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
         default: go(qkv_attention2_kernel<6, 3, GW_Q4_1>); break;
     }
 }
+
+#endif  // BERT_HIP_PHASES_ONLY
 
 }  // namespace bert_hip

@@ -649,6 +649,36 @@ def test_kernel_families_agree_end_to_end(make_model, knob, ftype, monkeypatch):
         assert cosine(base[i], alt[i]) > 1 - 1e-6, (knob, i, cosine(base[i], alt[i]))
 
 
+@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
+@pytest.mark.parametrize("B", [1, 3, 130, 512])
+def test_one_launch_gives_the_two_kernel_route_s_bits(make_model, ftype, B):
+    """Batches of full windows (every sentence exactly 128 tokens) run all layers in ONE launch (model_kernel.hip: a workgroup
+    carries its window through every layer, the window kernel and the layer tail as phases).  Same arithmetic per sentence
+    as two launches per layer — equal bits — and a sentence gives the same bits in a full-window batch and a ragged one."""
+    path, hp = make_model("minilm-l6", ftype, 0)
+    m = pybert.BertModel(path)
+    m.set_option("latency", "0")                             # (B = 1: the latency route would take it)
+    ids = gf.synthetic_token_ids(B, 128, hp.n_vocab, seed=77 + B)
+    cu = (np.arange(B + 1) * 128).astype(np.int32)
+    m.profile(True)
+    got = m.eval_packed(ids.reshape(-1), cu)
+    names = set(m.profile_report())
+    m.profile(False)
+    assert names == {"embed_ln", "model_kernel", "pool_normalize"}, names
+    m.set_option("one_launch", "0")
+    m.profile(True)
+    want = m.eval_packed(ids.reshape(-1), cu)
+    names = set(m.profile_report())
+    m.profile(False)
+    assert {"qkv_attention2", "layer_tail"} <= names and "model_kernel" not in names, names
+    assert np.array_equal(got, want), float(np.abs(got - want).max())
+    m.set_option("one_launch", "1")
+    ragged = m.eval_batch([ids[0], ids[0][:77], ids[B - 1]])               # not all full: two launches per layer
+    assert np.array_equal(ragged[0], got[0]) and np.array_equal(ragged[2], got[B - 1])
+    want0 = orc.Oracle(path).eval(ids[0])
+    assert cosine(got[0], want0) >= TIGHT_COS_GGML[ftype]
+
+
 def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
     """Growing batches make the engine reallocate (and zero-fill) its output / workspace buffers between
     evaluations; the fill must be complete before kernels of the next pass write them (it once was not: the
@@ -714,9 +744,16 @@ def test_full_size_batch_properties(make_model, ftype, B, q4, monkeypatch):
     out = m.eval_packed(ids.reshape(-1), cu)
     rep = m.profile_report()
     m.profile(False)
-    # two launches per layer: the fused projection + attention kernel and the token-owning layer tail, whatever the weights
-    assert set(rep) == {"embed_ln", "qkv_attention2", "layer_tail", "pool_normalize"}, sorted(rep)
-    assert rep["qkv_attention2"]["launches"] == hp.n_layer and rep["layer_tail"]["launches"] == hp.n_layer
+    # full windows (every sentence 128 tokens) and f16 images: ONE launch for all layers, a workgroup per window (the two fused
+    # kernels' bodies as phases); 4-bit-resident weights: two launches per layer (the window kernel and the layer tail)
+    if q4 == "fused":
+        assert set(rep) == {"embed_ln", "qkv_attention2", "layer_tail", "pool_normalize"}, sorted(rep)
+        assert rep["qkv_attention2"]["launches"] == hp.n_layer and rep["layer_tail"]["launches"] == hp.n_layer
+    else:
+        assert set(rep) == {"embed_ln", "model_kernel", "pool_normalize"}, sorted(rep)
+        assert rep["model_kernel"]["launches"] == 1
+        m.set_option("one_launch", "0")
+        assert np.array_equal(m.eval_packed(ids.reshape(-1), cu), out)          # the same bits as two launches per layer
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])

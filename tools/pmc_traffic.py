@@ -11,7 +11,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-NAMES = {"qkv_attention2_kernel": "qkv_attention2", "layer_tail_kernel": "layer_tail", "attention_mfma_kernel": "attention",
+NAMES = {"qkv_attention2_kernel": "qkv_attention2", "layer_tail_kernel": "layer_tail", "model_kernel": "model_kernel", "attention_mfma_kernel": "attention",
          "embed_ln_kernel": "embed_ln", "embed_ln_rows_kernel": "embed_ln", "pool_normalize_kernel": "pool_normalize",
          "layernorm_rows_kernel": "layernorm",
          # gemm256_kernel<EPI>: 0 = bias (Q|K|V), 1 = bias + GELU (FFN up), 2 = bias + residual (attention output AND FFN down:
