@@ -195,9 +195,14 @@ __device__ __forceinline__ void layernorm_runs(const float *row, const float *ga
         for (int g = 0; g < 4; ++g) {
             const int f = 32 * n + 8 * g + 4 * hi;
             const f32x4 gv = *(const f32x4 *)(gamma + f), bv = *(const f32x4 *)(beta + f);
+            // (f32 results, THEN f16: fused into v_fma_mixlo_f16 — one rounding — the compiler's choice depends on the kernel around
+            // it.  One opaque hand-over per run of four, so that the f32 math itself still packs into v_pk_fma_f32.)
+            f32x4 r;
 #pragma unroll
-            // (f32 result, THEN f16: fused into v_fma_mixlo_f16 — one rounding — the compiler's choice depends on the kernel around it)
-            for (int e = 0; e < 4; ++e) y[n][g][e] = (_Float16)rounded_f32(__builtin_fmaf(x[n][g][e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e])));
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(x[n][g][e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
+            asm("" : "+v"(r));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[n][g][e] = (_Float16)r[e];
         }
 }
 

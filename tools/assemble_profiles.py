@@ -37,16 +37,19 @@ pmc1, pmc2, pmc3, pmc3c3 = (read(f"pmc{n}_{tag}.txt") for n in ("1", "2", "3", "
 h1, r1 = table(pmc1)
 h3, r3 = table(pmc3)
 busy = {}
-for k in ("layer_tail", "qkv_attention2"):
-    m = float(find(r1, k)[next(c for c in h1 if "MFMA_BUSY" in c)])
-    gui = float(find(r3, k)[next(c for c in h3 if "GRBM" in c)]) / 8          # summed over the 8 XCDs
-    busy[k] = (m, gui, m / (1024 * gui))
+for k in ("model_kernel", "layer_tail", "qkv_attention2"):
+    try:
+        m = float(find(r1, k)[next(c for c in h1 if "MFMA_BUSY" in c)])
+        gui = float(find(r3, k)[next(c for c in h3 if "GRBM" in c)]) / 8          # summed over the 8 XCDs
+        busy[k] = (m, gui, m / (1024 * gui))
+    except StopIteration:
+        pass
 bench = json.loads(read(f"bench_{tag}.log"))
 hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
-       f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers, 2 launches per layer (qkv_attention2 + layer_tail)\n"
-       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), HIP events layer_tail {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
-       f"# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): layer_tail {busy['layer_tail'][0] / 1e6:.2f} M / (1024 x {busy['layer_tail'][1] / 1e3:.1f} k) = {busy['layer_tail'][2]:.2f}, "
-       f"qkv_attention2 {busy['qkv_attention2'][0] / 1e6:.2f} M / (1024 x {busy['qkv_attention2'][1] / 1e3:.1f} k) = {busy['qkv_attention2'][2]:.2f} (round 2: 0.39 / 0.33)\n")
+       f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers: ONE launch for all layers (model_kernel: a workgroup per window, qkv_attention2 + layer_tail as phases)\n"
+       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), HIP events {bench['roofline']['kernel']} {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
+       "# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): " +
+       ", ".join(f"{k} {v[0] / 1e6:.2f} M / (1024 x {v[1] / 1e3:.1f} k) = {v[2]:.2f}" for k, v in busy.items()) + " (two launches per layer, earlier this round: layer_tail 0.41, qkv_attention2 0.34)\n")
 c3 = bench["also"]["config3"]
 with open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w") as f:
     f.write(hdr + read(f"stats_{tag}.txt") +
