@@ -113,7 +113,8 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, one_launch_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
+    int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
 
     // profiling

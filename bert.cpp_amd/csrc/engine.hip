@@ -213,7 +213,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     // | naive (the generic kernels: any shape, row-major f16 images); finer switches: bert_hip_set_option
     if (const char *k = getenv("BERT_HIP_KERNELS")) {
         if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
-        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = e->one_launch_ = false;
+        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false, e->one_launch_ = 0;
     }
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
@@ -310,7 +310,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
-    else if (key == "one_launch") one_launch_ = value != "0";
+    else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -413,10 +413,16 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     // cu_seqlens when packing can pay — sentences on average clearly shorter than max_len; for full-length batches the
     // uniform rule (max_len-sized places) gives the same windows without the extra launch
     const int *d_n_windows = nullptr;
-    if (!d_windows && qkv2_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok &&
-        qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len)) {
+    const bool fused_windows = qkv2_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok && qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
+    // all layers in one launch (model_kernel.hip): a workgroup carries its window through every layer
+    const bool one_launch_ok = fused_windows && one_launch_ && tail_ && !d_hidden && !(latency_ && T <= 128) &&
+                               model_kernel_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w, hp_.n_layer, nh, dh, max_len);
+    const bool full_windows = (long long)B * 128 == T;
+    if (!d_windows && fused_windows) {
         const int spw = qkv_attention2_sentences_per_window(max_len), uniform = (B + spw - 1) / spw;
-        if (4ll * uniform * 128 > 5 * ((long long)T + 8ll * B)) {
+        // (forced one-launch: the kernel takes a window list or one sentence per window — its layer-tail phase needs a window's
+        // tokens to be at most 128 whatever the sentences' lengths turn out to be)
+        if (4ll * uniform * 128 > 5 * ((long long)T + 8ll * B) || (one_launch_ok && one_launch_ == 2 && spw > 1 && !full_windows)) {
             int *count = status_.as<int>() + 1;
             timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, s); });
             d_windows = windows_.as<int2>();
@@ -426,6 +432,14 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             // a neighbour its window
             n_windows = qkv_attention2_max_windows(B, T);
         }
+    }
+    // When it pays: the layer-tail phase costs a window 128 rows' time however few tokens it holds, the layer-tail KERNEL runs
+    // on the packed tokens — 0.32 + 0.68 fill against 0.94 (full windows: +6.7 %): from a fill of 0.91.  The window count is
+    // known for the caller's list and for one sentence per window, not for a list built on the device.
+    bool one_launch_pays = full_windows || one_launch_ == 2;
+    if (!one_launch_pays && !d_n_windows) {
+        const long long n_win = d_windows ? n_windows : B;
+        one_launch_pays = (d_windows || qkv_attention2_sentences_per_window(max_len) == 1) && 100ll * T >= 95ll * 128 * n_win;
     }
     // The latency route (skinny.hip): at most 128 tokens = one window of the fused kernels, which would keep one CU of 256 busy
     // per launch.  Same bits per sentence (the route must not show in the results), seven short launches per layer.
@@ -460,11 +474,10 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             tap(il + 1);
         }
     }
-    // Batches of FULL windows (every sentence exactly 128 tokens: T = 128 B): all layers in one launch, a workgroup per window
-    // (model_kernel.hip) — the two fused kernels' bodies as phases, no kernel boundary to put the workgroups back in step.
-    // (T = 128 B with no sentence over 128 tokens: every window is one whole sentence, whatever list the caller built)
-    const bool one_launch = !skinny && one_launch_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && !d_hidden &&
-                            model_kernel_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w, hp_.n_layer, nh, dh, B, T, max_len);
+    // All layers in one launch, a workgroup per window (model_kernel.hip) — the two fused kernels' bodies as phases, no kernel
+    // boundary to put the workgroups back in step.  Batches of FULL windows (every sentence exactly 128 tokens: T = 128 B) take the
+    // specialised form (every window is one whole sentence, whatever list the caller built).
+    const bool one_launch = !skinny && one_launch_ok && one_launch_pays;
     if (one_launch) {
         ModelLayerWeights mw[16];
         for (int il = 0; il < hp_.n_layer; ++il) {
@@ -473,7 +486,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                       L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(), L.ln_out_b.as<float>()};
         }
         timed("model_kernel", hp_.n_layer * (2.0 * Td * 3 * H * H + att_flops + 2.0 * Td * H * H + 4.0 * Td * H * I), s, [&] {
-            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, nh, s);
+            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, s);
         });
     }
     for (int il = 0; !skinny && !one_launch && il < hp_.n_layer; ++il) {

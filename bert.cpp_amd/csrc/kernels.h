@@ -87,17 +87,19 @@ bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const Gemm
 void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, const half_t *ctx, const half_t *x,
                        const float *bo, const float *g1, const float *be1, const float *b1, const float *b2,
                        const float *g2, const float *be2, half_t *out, int M_pad, hipStream_t stream);
-// All encoder layers of a batch of FULL windows (every sentence exactly 128 tokens) in one launch (model_kernel.hip): a
-// workgroup carries its window through every layer — the window kernel's and the layer tail's bodies as phases, same bits.
+// All encoder layers of a batch in one launch (model_kernel.hip): a workgroup carries its window (whole sentences, at most 128
+// tokens between them) through every layer — the window kernel's and the layer tail's bodies as phases, same bits.
 struct ModelLayerWeights {
     const GemmWeight *Wqkv, *Wo, *W1, *W2;
     const float *bqkv, *bo, *g1, *be1, *b1, *b2, *g2, *be2;
 };
 bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, int n_layer,
-                            int n_head, int d_head, int n_sentences, int n_tokens, int max_len);
-// x: in = embeddings + LayerNorm, out = the last layer's output; ctx: workspace [T][H]
+                            int n_head, int d_head, int max_len);
+// x: in = embeddings + LayerNorm, out = the last layer's output; ctx: workspace [T][H].  groups / n_groups / n_groups_dev: the
+// window list as for launch_qkv_attention2 (nullptr: one sentence per window); n_tokens = 128 n_sentences selects the form
+// specialised for full windows.
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
-                         int n_head, hipStream_t stream);
+                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, hipStream_t stream);
 // The latency route (skinny.hip): the weight mat-muls of a layer split by output features AND token blocks over up to 192
 // one-wave workgroups, for batches of at most 128 tokens; same bits per sentence as qkv_attention2 + layer_tail.
 // mode: 0 QKV projection (-> f16), 1 out-projection (+ x + bo -> f32), 2 up-projection + GELU (-> f16, fragment order),

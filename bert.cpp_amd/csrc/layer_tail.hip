@@ -155,8 +155,10 @@ __device__ __forceinline__ f32x16 mfma16(const f16x8 &a, const f16x8 &b, const f
 
 // (the kernel's body as a device function of (arguments, the workgroup's LDS, 128-token block index): model_kernel.hip runs it as
 // one phase of a launch that carries a window through all layers)
-template <int NT, int WT>
-__device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, const int block, const int tid) {
+// RAGGED: the block is rows tok0 .. tok0 + rows - 1 only (a window of whole sentences with fewer than 128 tokens; the rows behind
+// belong to another workgroup): the loads of the missing rows repeat the last one, their stores are skipped.
+template <int NT, int WT, bool RAGGED = false>
+__device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, const int tok0, const int rows, const int tid) {
     constexpr bool Q4 = WT != GW_F16;
     constexpr int VMQ = Q4 ? 63 : 0;                          // (q4: no LDS-DMA in flight, nothing for a barrier to wait for)
     constexpr int H = 128 * NT, NBH = 2 * NT, NB = 4 * NT, NQ = 8 * NT, NYH = 4 * NT;
@@ -168,7 +170,8 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int t = wave & 3, role = wave >> 2;                 // token block; 0 = U (up-projection + GELU), 1 = D (down-projection)
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tok_w = block * 128 + t * 32;                   // first token of this pair
+    const int tok_w = tok0 + t * 32;                          // first token of this pair
+    const int row_l = RAGGED ? tok0 + min(t * 32 + l31, rows - 1) : tok_w + l31;      // the lane's row of x / ctx
 
     char *ringU = smem;                                       // 3 x 16 KiB
     char *ringD = smem + 3 * LT_TILE;                         // 3 x 16 KiB
@@ -205,7 +208,7 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
     f32x16 accp[NBH];
     f16x4 xv[NBH][4];
     {
-        const half_t *xr = a.x + (size_t)(tok_w + l31) * H + role * 64 + 4 * hi;
+        const half_t *xr = a.x + (size_t)row_l * H + role * 64 + 4 * hi;
 #pragma unroll
         for (int b = 0; b < NBH; ++b)
 #pragma unroll
@@ -214,7 +217,7 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
     // attention context of the pair's tokens as B fragments, straight into registers (k order as stored)
     f16x8 bf[NQ];
     {
-        const half_t *cw = a.ctx + (size_t)(tok_w + l31) * H + 8 * hi;
+        const half_t *cw = a.ctx + (size_t)row_l * H + 8 * hi;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bf[q] = *(const f16x8 *)(cw + 16 * q);
     }
@@ -467,6 +470,7 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
     // ================================ rows -> HBM (both waves of the pair, alternate 1 KiB pieces) ================================
     // (called at the end of EACH role's branch, which then returns: with a common tail behind the branches the register
     // allocator carries U's fragments "through" D's branch — stores in front of D's loop, dead reloads behind it)
+    typedef unsigned store_u32x4 __attribute__((ext_vector_type(4)));
     auto store_rows = [&]() __attribute__((always_inline)) {
         LT_STAMP(tlU, 394);
         const char *S = smem + t * (64 * H);
@@ -475,6 +479,10 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
         // 16-byte unit (token, 8-feature chunk c8) of the output = bytes h2*8.. of the fragments (q, token) and
         // (q, token + 32), q = c8 >> 1, h2 = c8 & 1
         half_t *ow = a.out + (size_t)tok_w * H;
+        // RAGGED: a buffer of the pair's rows that exist — the hardware drops the stores behind its end (a branch around each
+        // store costs the combined translation unit 450 bytes of scratch)
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t out_rows =
+            __builtin_amdgcn_make_buffer_rsrc(ow, 0, max(min(rows - t * 32, 32), 0) * H * 2, 0x00020000);
 #pragma unroll
         for (int st2 = 0; st2 < H / 32; ++st2) {
             const int st = 2 * st2 + role;
@@ -485,7 +493,8 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] = lo[e]; o[4 + e] = hi4[e]; }
-            *(f16x8 *)(ow + (size_t)tok * H + c8 * 8) = o;
+            if constexpr (RAGGED) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(store_u32x4, o), out_rows, (tok * H + c8 * 8) * 2, 0, 0);
+            else *(f16x8 *)(ow + (size_t)tok * H + c8 * 8) = o;
         }
 #ifdef BERT_HIP_TIMELINE
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -891,7 +900,7 @@ __device__ __forceinline__ void layer_tail_body(const TailArgs &a, char *smem, c
 template <int NT, int WT>
 __global__ __launch_bounds__(512) void layer_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    layer_tail_body<NT, WT>(a, smem, (int)blockIdx.x, (int)threadIdx.x);
+    layer_tail_body<NT, WT>(a, smem, (int)blockIdx.x * 128, 128, (int)threadIdx.x);
 }
 
 static size_t layer_tail_lds(int H, int I) {

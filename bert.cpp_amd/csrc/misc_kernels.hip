@@ -2,6 +2,7 @@
 // LayerNorm, stand-alone LayerNorm, mean-pool + L2 normalise.  One 64-lane wavefront per token row
 // with __shfl_xor reductions; no LDS needed.
 #include "kernels.h"
+#include "pool_normalize.h"
 
 namespace bert_hip {
 
@@ -338,59 +339,13 @@ void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, i
 }
 
 // reference bert.cpp:904-913: mean over all N tokens (mat-vec with a 1/N vector), then y / ||y||_2.
-// One workgroup per sentence; wave w sums tokens w, w+4, ... over coalesced half2 row reads, the
-// four partial rows are combined through LDS.
+// One workgroup per sentence (pool_normalize.h: the body, shared with the epilogue of model_kernel.hip).
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, const int32_t *cu_seqlens, int H,
                                                              int max_len, int *status, float *out) {
     extern __shared__ float part[];          // [4][H] partial sums, then red[4]
-    const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b = blockIdx.x;
     const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
-    if (n <= 0 || n > max_len) {
-        // the batch does not keep the caller's promise (bert_hip_eval_packed_device: max_len): the kernels upstream were
-        // chosen and sized for max_len, so this sentence's result is not trustworthy -> NaN row, status word
-        for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] = __builtin_nanf("");
-        if (tid == 0 && status) atomicOr(status, 1);
-        return;
-    }
-    const float invn = 1.0f / (float)n;
-    if (H % 8 == 0) {
-        // 16-byte runs per lane (same per-element summation order as the pair loop below)
-        for (int c = lane; c < H / 8; c += 64) {
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-            for (int t = wave; t < n; t += 4) {
-                const f16x8m v = *(const f16x8m *)(x + (size_t)(tok0 + t) * H + 8 * c);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += (float)v[i] * invn;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) part[wave * H + 8 * c + i] = acc[i];
-        }
-    } else {
-        for (int e = 2 * lane; e < H; e += 128) {
-            float a0 = 0.f, a1 = 0.f;
-#pragma unroll 8
-            for (int t = wave; t < n; t += 4) {
-                const f16x2 v = *(const f16x2 *)(x + (size_t)(tok0 + t) * H + e);
-                a0 += (float)v[0] * invn; a1 += (float)v[1] * invn;
-            }
-            part[wave * H + e] = a0; part[wave * H + e + 1] = a1;
-        }
-    }
-    __syncthreads();
-    float sq = 0.f;
-    for (int e = tid; e < H; e += 256) {
-        const float a = (part[e] + part[H + e]) + (part[2 * H + e] + part[3 * H + e]);
-        part[e] = a;
-        sq += a * a;
-    }
-    sq = wave_sum(sq);
-    __syncthreads();
-    float *red = part + 4 * H;
-    if (lane == 0) red[wave] = sq;
-    __syncthreads();
-    const float scale = 1.0f / sqrtf((red[0] + red[1]) + (red[2] + red[3]));
-    for (int e = tid; e < H; e += 256) out[(size_t)b * H + e] = part[e] * scale;
+    pool_normalize_sentence(x, tok0, n, b, H, max_len, status, out, part, (int)threadIdx.x, true);
 }
 
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status,

@@ -33,16 +33,34 @@ struct ModelLayerArgs {              // what differs from layer to layer
 struct ModelArgs {
     half_t *x, *ctx;                 // [T][H] hidden state (in: embeddings + LN; out: the last layer's output), attention context
     const int32_t *cu;
+    const int2 *groups;              // RAGGED: per window {first sentence, count} (qkv_attention2.hip), or nullptr: one sentence per window
+    const int *n_groups;             // RAGGED: device word holding the number of windows (the grid is an upper bound), or nullptr
     int n_layer, n_head, n_sent, I;
     ModelLayerArgs layer[MODEL_MAX_LAYERS];
 };
 
 }  // namespace
 
-template <int NT>
+// RAGGED: windows of whole sentences with up to 128 tokens between them (the window phase's slots: every sentence starts at a
+// multiple of 16), whose rows of x / ctx are tok0 .. tok0 + rows - 1 of the packed batch: the layer-tail phase runs on those.
+template <int NT, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int window = (int)blockIdx.x;              // = sentence = 128-token block
+    const int window = (int)blockIdx.x;              // full windows: = sentence = 128-token block
+    int tok0 = window * 128, rows = 128;
+    if constexpr (RAGGED) {
+        int first = window, count = 1;
+        if (m.groups) {
+            if (m.n_groups && window >= *m.n_groups) return;
+            const int2 g = m.groups[window];
+            first = g.x; count = g.y;
+        }
+        if (count <= 0 || first >= m.n_sent) return;
+        tok0 = m.cu[first];
+        // (a sentence longer than a window breaks the caller's promise: its rows behind the 128th are not computed — it is the
+        // one that gets a NaN row from the length guard of the pooling kernel)
+        rows = min(m.cu[first + count] - tok0, 128);
+    }
     // The thread id is REBUILT per phase from the wave's index (a scalar register) and the lane count: with threadIdx.x itself
     // the compiler hoists both phases' lane-dependent address arithmetic out of the layer loop — eighty registers' worth —
     // and spills it; even one vector register alive across the phases is one more than the layer tail has (a scratch reload
@@ -58,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         int tid = thread_id();
         {
             Qkv2Args q;
-            q.x = m.x; q.w = L.wqkv; q.qs = nullptr; q.sc = nullptr; q.bias = L.bqkv; q.cu = m.cu; q.groups = nullptr; q.n_groups = nullptr;
+            q.x = m.x; q.w = L.wqkv; q.qs = nullptr; q.sc = nullptr; q.bias = L.bqkv; q.cu = m.cu; q.groups = RAGGED ? m.groups : nullptr; q.n_groups = nullptr;
             q.out = m.ctx; q.n_head = m.n_head; q.n_sent = m.n_sent; q.spw = 1;
             qkv_attention2_body<2 * NT, NT, GW_F16>(q, smem, window, tid);
         }
@@ -72,7 +90,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
             t.ctx = m.ctx; t.x = m.x; t.wo = L.wo; t.w1p = L.w1p; t.w2p = L.w2p;
             t.wo_qs = t.w1_qs = t.w2_qs = nullptr; t.wo_sc = t.w1_sc = t.w2_sc = nullptr;
             t.bo = L.bo; t.g1 = L.g1; t.be1 = L.be1; t.b1 = L.b1; t.b2 = L.b2; t.g2 = L.g2; t.be2 = L.be2; t.out = m.x; t.I = m.I;
-            layer_tail_body<NT, GW_F16>(t, smem, window, tid);
+            layer_tail_body<NT, GW_F16, RAGGED>(t, smem, tok0, rows, tid);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -80,17 +98,20 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
     }
 }
 
+// full: every sentence exactly 128 tokens (T = 128 B: the specialised form); otherwise windows of whole sentences — the caller's
+// list (`groups`), or one sentence per window when the promised max_len leaves room for no second one
 bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, int n_layer,
-                            int n_head, int d_head, int n_sentences, int n_tokens, int max_len) {
+                            int n_head, int d_head, int max_len) {
     const int H = n_head * d_head;
-    return n_layer <= MODEL_MAX_LAYERS && (H == 256 || H == 384) && max_len == 128 && (long long)n_sentences * 128 == n_tokens &&
+    return n_layer <= MODEL_MAX_LAYERS && (H == 256 || H == 384) && max_len >= 1 && max_len <= 128 &&
            Wqkv.type == GW_F16 && Wo.type == GW_F16 && qkv_attention2_supported(Wqkv, n_head, d_head, max_len) && layer_tail_supported(Wo, W1, W2);
 }
 
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
-                         int n_head, hipStream_t stream) {
+                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, hipStream_t stream) {
     ModelArgs m;
-    m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N;
+    m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.groups = groups; m.n_groups = n_groups_dev;
+    m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N;
     for (int l = 0; l < n_layer; ++l) {
         const ModelLayerWeights &s = layers[l];
         ModelLayerArgs &d = m.layer[l];
@@ -100,12 +121,15 @@ void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x
     const int H = layers[0].W1->K, KT = H / 64, GB = KT / 2;
     const size_t lds_q = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * H * sizeof(float);
     const size_t lds = std::max(lds_q, layer_tail_lds(H, m.I));
+    const bool full = (long long)n_sentences * 128 == n_tokens;      // (with no sentence over 128 tokens: every window is one whole sentence)
+    const int grid = full || !groups ? n_sentences : n_groups;
     static DeviceFlags configured[4];
     auto go = [&](auto kernel, int which) {
         configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        hipLaunchKernelGGL(kernel, dim3(n_sentences), dim3(512), lds, stream, m);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, m);
     };
-    if (H == 256) go(model_kernel<2>, 2); else go(model_kernel<3>, 3);
+    if (full) { if (H == 256) go(model_kernel<2, false>, 0); else go(model_kernel<3, false>, 1); }
+    else { if (H == 256) go(model_kernel<2, true>, 2); else go(model_kernel<3, true>, 3); }
 }
 
 }  // namespace bert_hip

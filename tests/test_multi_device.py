@@ -161,12 +161,15 @@ def test_gather_entry_point_matches_the_host_api(make_model, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_device_api_guards(make_model, capfd):
+@pytest.mark.parametrize("one_launch", ["1", "2"])
+def test_device_api_guards(make_model, capfd, one_launch):
     """bert_hip_eval_packed_device trusts max_len for kernel selection; a batch that breaks the promise must not produce
-    silent garbage: NaN rows for the offending sentences and bert_hip_check() == 1."""
+    silent garbage: NaN rows for the offending sentences and bert_hip_check() == 1 — on the default route and with all
+    layers in one launch whatever the windows' fill (one_launch=2: model_kernel.hip on ragged windows)."""
     hip = _Hip()
     path, hp = make_model("minilm-l6", "f16", 0)
     m = pybert.BertModel(path)
+    m.set_option("one_launch", one_launch)
     lens = [20, 100, 64, 7]
     cu = _cu(lens)
     T, H = int(cu[-1]), hp.n_embd
@@ -187,6 +190,17 @@ def test_device_api_guards(make_model, capfd):
     # a max_len that cannot hold the tokens at all is refused on the host
     with pytest.raises(RuntimeError):
         m.eval_packed_device(d_t, d_cu, 4, T, 16, out, 0)
+    # promise 128, deliver 200 (longer than a window): the same
+    lens2 = [20, 200, 64, 7, 128, 90]
+    cu2 = _cu(lens2)
+    toks2 = np.random.default_rng(1).integers(1000, hp.n_vocab, size=int(cu2[-1])).astype(np.int32)
+    want2 = m.eval_batch([toks2[cu2[i]:cu2[i + 1]] for i in (0, 2, 3, 4, 5)])
+    out2 = hip.upload(np.full((6, H), 7.0, np.float32))
+    m.eval_packed_device(hip.upload(toks2), hip.upload(cu2), 6, int(cu2[-1]), 128, out2, 0)
+    assert m.check() == 1
+    got2 = hip.download(out2, (6, H))
+    assert np.isnan(got2[1]).all() and np.array_equal(got2[[0, 2, 3, 4, 5]], want2)
+    capfd.readouterr()
     # two streams, back to back: the context serialises its passes itself
     s1, s2 = hip.stream(), hip.stream()
     o1, o2 = hip.malloc(4 * H * 4), hip.malloc(4 * H * 4)
@@ -194,6 +208,68 @@ def test_device_api_guards(make_model, capfd):
         m.eval_packed_device(d_t, d_cu, 4, T, 128, o1, s1)
         m.eval_packed_device(d_t, d_cu, 4, T, 128, o2, s2)
     assert np.array_equal(hip.download(o1, (4, H)), want) and np.array_equal(hip.download(o2, (4, H)), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,ftype", [("minilm-l6", "f16"), ("minilm-l12", "q4_1"), ("h256-l3", "f16")])
+def test_one_launch_on_ragged_windows(make_model, dims, ftype):
+    """model_kernel.hip also takes windows that are not full (whole sentences, at most 128 tokens between them: its layer-tail
+    phase runs on the window's rows of the packed batch, the stores behind them dropped by a buffer descriptor's range
+    check).  Same bits as two launches per layer, with the caller's window list (host API), the list built on the device and
+    one sentence per window.  The engine takes the route by itself only for well-filled windows (the tail phase costs 128
+    rows' time whatever the window holds: 1.15 M against 1.49 M sentences/s on the bench's mixed-length batch), one_launch=2
+    forces it."""
+    gf.MODEL_DIMS.setdefault("h256-l3", gf.BertHParams(1000, 128, 256, 1024, 8, 3))
+    hip = _Hip()
+    path, hp = make_model(dims, ftype, 0)
+    m = pybert.BertModel(path)
+    m.set_option("latency", "0")
+    rng = np.random.default_rng(5)
+    cases = {"mixed": rng.integers(1, 129, size=300), "ones": np.ones(70, dtype=np.int64), "16s": np.full(40, 16), "17s": np.full(33, 17),
+             "two": np.array([128, 3]), "max 64": rng.integers(40, 65, size=50), "32s": np.full(64, 32), "one": np.array([5]),
+             "127s": np.full(9, 127), "many": rng.integers(3, 129, size=2000)}
+    H = hp.n_embd
+    for name, lens in cases.items():
+        cu = _cu(lens)
+        T, B, ml = int(cu[-1]), len(lens), int(np.max(lens))
+        toks = rng.integers(0, hp.n_vocab, size=T).astype(np.int32)
+        m.set_option("one_launch", "0")
+        want = m.eval_packed(toks, cu)
+        m.set_option("one_launch", "2")
+        m.profile(True)
+        got = m.eval_packed(toks, cu)
+        names = set(m.profile_report())
+        m.profile(False)
+        assert "model_kernel" in names and not {"qkv_attention2", "layer_tail"} & names, (name, names)
+        assert np.array_equal(got, want), (name, "host windows")
+        d_t, d_cu, out = hip.upload(toks), hip.upload(cu), hip.upload(np.full((B, H), 7.0, np.float32))
+        m.reserve(T, B)
+        for promised in (ml, 128):                          # (windows built on the device, or one sentence per window)
+            m.profile(True)
+            m.eval_packed_device(d_t, d_cu, B, T, promised, out, 0)
+            got = hip.download(out, (B, H))
+            names = set(m.profile_report())
+            m.profile(False)
+            assert m.check() == 0 and "model_kernel" in names and not {"qkv_attention2", "layer_tail"} & names, (name, promised, names)
+            assert np.array_equal(got, want), (name, promised)
+    # by itself: windows filled to 95 % and more
+    lens = rng.integers(123, 129, size=40)
+    cu = _cu(lens)
+    toks = rng.integers(0, hp.n_vocab, size=int(cu[-1])).astype(np.int32)
+    m.set_option("one_launch", "0")
+    want = m.eval_packed(toks, cu)
+    m.set_option("one_launch", "1")
+    m.profile(True)
+    got = m.eval_packed(toks, cu)
+    names = set(m.profile_report())
+    m.profile(False)
+    assert "model_kernel" in names and np.array_equal(got, want), names
+    short = [toks[cu[i]:cu[i + 1]][:90] for i in range(20)]                      # fill 0.70: two launches per layer
+    m.profile(True)
+    got = m.eval_batch(short)
+    names = set(m.profile_report())
+    m.profile(False)
+    assert "model_kernel" not in names and {"qkv_attention2", "layer_tail"} <= names, names
 
 
 @pytest.mark.gpu
