@@ -149,9 +149,11 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
     model.reserve(T, B)
 
+    h_out = np.empty((B, H), dtype=np.float32) if cfg.get("host_step") else None
+
     def step():
         if cfg.get("host_step"):
-            d_out.copy_(torch.from_numpy(model.eval_packed(flat, cu)))
+            model.eval_packed(flat, cu, out=h_out)            # (the caller's rows, as bert_eval_batch's `float **batch_embeddings`)
             return
         model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_out.data_ptr(), stream.cuda_stream)
         if world > 1:
@@ -169,7 +171,7 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     regions = timed_regions(step, steps, warmup if warmup is not None else args.warmup, repeat or args.repeat,
                             lambda: torch.cuda.synchronize(device), dist.barrier if world > 1 else None, reduce_max)
     dt = float(np.median(regions))
-    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=d_out, steps=steps, regions=regions,
+    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=torch.from_numpy(h_out) if h_out is not None else d_out, steps=steps, regions=regions,
                value=world * B * steps / dt, ms_per_step=1e3 * dt / steps, step=step, tokens=T, max_len=max_len)
     return res
 
@@ -219,16 +221,16 @@ def host_api_rate(res, calls=None):
     m, flat, cu = res["model"], res["flat"], res["cu"]
     B = len(cu) - 1
     calls = calls or max(5, min(200, int(0.5 / max(res["ms_per_step"] * 1e-3, 1e-4))))
+    out = np.empty((B, res["hp"].n_embd), dtype=np.float32)       # the caller's rows (bert.h: `float **batch_embeddings`), reused like a C caller's
     for _ in range(2):
-        out = m.eval_packed(flat, cu)
+        m.eval_packed(flat, cu, out=out)
     ts = []
     for _ in range(calls):
         t0 = time.perf_counter()
-        m.eval_packed(flat, cu)
+        m.eval_packed(flat, cu, out=out)
         ts.append(time.perf_counter() - t0)
     med = float(np.median(ts))
-    # (min / max: the 5th and 95th percentile call — a single call in a few hundred takes tens of milliseconds when the host
-    # allocator has to map fresh pages for the result array)
+    # (min / max: the 5th and 95th percentile call)
     return {"value": B / med, "unit": "sentences/s", "ms_per_call": 1e3 * med, "min": B / float(np.percentile(ts, 95)),
             "max": B / float(np.percentile(ts, 5)), "calls": calls,
             "entry": "bert_hip_eval_packed (host ids -> host embeddings: pinned staging, one H2D copy, forward, rows written into pinned host memory, blocking)"}, out

@@ -97,9 +97,11 @@ bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const 
                             int n_head, int d_head, int max_len);
 // x: in = embeddings + LayerNorm, out = the last layer's output; ctx: workspace [T][H].  groups / n_groups / n_groups_dev: the
 // window list as for launch_qkv_attention2 (nullptr: one sentence per window); n_tokens = 128 n_sentences selects the form
-// specialised for full windows.
+// specialised for full windows.  pooled != nullptr: the workgroups also pool and normalise their sentences (launch_pool_normalize's
+// arguments and bits: [n_sentences][H] f32, max_len, status word).
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
-                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, hipStream_t stream);
+                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, float *pooled, int max_len,
+                         int *status, hipStream_t stream);
 // The latency route (skinny.hip): the weight mat-muls of a layer split by output features AND token blocks over up to 192
 // one-wave workgroups, for batches of at most 128 tokens; same bits per sentence as qkv_attention2 + layer_tail.
 // mode: 0 QKV projection (-> f16), 1 out-projection (+ x + bo -> f32), 2 up-projection + GELU (-> f16, fragment order),

@@ -1,5 +1,7 @@
-// model_kernel.hip — ONE launch for all encoder layers of a batch of FULL windows (every sentence exactly 128 tokens, f16
-// weights, H = 256 / 384, d_head 32): reference bert.cpp:816-901, the whole loop over layers.
+// model_kernel.hip — ONE launch for all encoder layers of a batch (f16 images, H = 256 / 384, d_head 32, sentences of at most
+// 128 tokens) plus the pooling: reference bert.cpp:816-913, the whole loop over layers and what follows it.  Two forms: FULL
+// windows (every sentence exactly 128 tokens: a window is a sentence is a 128-token block) and RAGGED ones (whole sentences
+// with at most 128 tokens between them: the layer-tail phase runs on the window's rows of the packed batch).
 //
 // Why: with one kernel per layer half (qkv_attention2, layer_tail) a 256-sentence step is ONE workgroup per CU per launch,
 // all 256 in lockstep — everybody's load burst (ctx + x: 48 MB at the HBM limit), everybody's compute, everybody's store
@@ -19,6 +21,7 @@
 #include "qkv_attention2.hip"
 #include "layer_tail.hip"
 #undef BERT_HIP_PHASES_ONLY
+#include "pool_normalize.h"
 
 namespace bert_hip {
 
@@ -36,6 +39,9 @@ struct ModelArgs {
     const int2 *groups;              // RAGGED: per window {first sentence, count} (qkv_attention2.hip), or nullptr: one sentence per window
     const int *n_groups;             // RAGGED: device word holding the number of windows (the grid is an upper bound), or nullptr
     int n_layer, n_head, n_sent, I;
+    float *pooled;                   // [n_sent][H] f32: the sentences' pooled, normalised rows (the workgroup pools its window itself), or nullptr
+    int *status;                     // pooling's status word (a sentence outside [1, max_len])
+    int max_len;
     ModelLayerArgs layer[MODEL_MAX_LAYERS];
 };
 
@@ -47,9 +53,8 @@ template <int NT, bool RAGGED>
 __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int window = (int)blockIdx.x;              // full windows: = sentence = 128-token block
-    int tok0 = window * 128, rows = 128;
+    int tok0 = window * 128, rows = 128, first = window, count = 1;
     if constexpr (RAGGED) {
-        int first = window, count = 1;
         if (m.groups) {
             if (m.n_groups && window >= *m.n_groups) return;
             const int2 g = m.groups[window];
@@ -71,7 +76,8 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         asm volatile("" : "+v"(ln), "+s"(w));
         return w * 64 + ln;
     };
-    for (int l = 0; l < m.n_layer; ++l) {
+    const int n_layer = rows > 0 ? m.n_layer : 0;    // (a window of empty sentences: nothing to compute, NaN rows from the pooling below)
+    for (int l = 0; l < n_layer; ++l) {
         const ModelLayerArgs &L = m.layer[l];
         int tid = thread_id();
         {
@@ -96,6 +102,16 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    // ---- mean-pool + L2 normalise of the window's sentences (pool_normalize.h: the pooling kernel's body and bits), while the
+    // other workgroups are still in their layers: the rows were written by this workgroup and sit in the L2
+    if (m.pooled) {
+        const int tid = thread_id();
+        for (int j = 0; j < count; ++j) {
+            const int b = first + j, t0 = m.cu[b], n = m.cu[b + 1] - t0;
+            pool_normalize_sentence(m.x, t0, n, b, 128 * NT, m.max_len, m.status, m.pooled, (float *)smem, tid, tid < 256);
+            __syncthreads();                                  // (the next sentence reuses the partial rows)
+        }
+    }
 }
 
 // full: every sentence exactly 128 tokens (T = 128 B: the specialised form); otherwise windows of whole sentences — the caller's
@@ -108,8 +124,10 @@ bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const 
 }
 
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
-                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, hipStream_t stream) {
+                         int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, float *pooled, int max_len,
+                         int *status, hipStream_t stream) {
     ModelArgs m;
+    m.pooled = pooled; m.status = status; m.max_len = max_len;
     m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.groups = groups; m.n_groups = n_groups_dev;
     m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N;
     for (int l = 0; l < n_layer; ++l) {

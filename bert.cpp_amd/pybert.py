@@ -289,11 +289,14 @@ class BertModel:
         return out
 
     # ---- bert_hip.h -----------------------------------------------------------------------
-    def eval_packed(self, tokens: np.ndarray, cu_seqlens: np.ndarray) -> np.ndarray:
+    def eval_packed(self, tokens: np.ndarray, cu_seqlens: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """out: the caller's result rows, as in the C ABI (bert.h: `float **batch_embeddings`); a fresh NaN-filled array if None."""
         tokens = np.ascontiguousarray(tokens, dtype=np.int32)
         cu = np.ascontiguousarray(cu_seqlens, dtype=np.int32)
         B = len(cu) - 1
-        out = np.full((B, self.n_embd), np.nan, dtype=np.float32)
+        if out is None:
+            out = np.full((B, self.n_embd), np.nan, dtype=np.float32)
+        assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (B, self.n_embd)
         r = self.lib.bert_hip_eval_packed(self.ctx, _i32p(tokens), _i32p(cu), B, _f32p(out))
         if r != 0:
             raise RuntimeError(f"bert_hip_eval_packed failed: {r}")

@@ -107,7 +107,8 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
- * of the fused family, "gemm" / "attn" = "mfma" | "naive", "chunk_tokens" = n.                                             */
+ * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "chunk_tokens" = n.                                         */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);

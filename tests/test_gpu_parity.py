@@ -664,7 +664,7 @@ def test_one_launch_gives_the_two_kernel_route_s_bits(make_model, ftype, B):
     got = m.eval_packed(ids.reshape(-1), cu)
     names = set(m.profile_report())
     m.profile(False)
-    assert names == {"embed_ln", "model_kernel", "pool_normalize"}, names
+    assert names == {"embed_ln", "model_kernel"}, names     # (the workgroups pool their sentences themselves)
     m.set_option("one_launch", "0")
     m.profile(True)
     want = m.eval_packed(ids.reshape(-1), cu)
@@ -750,7 +750,7 @@ def test_full_size_batch_properties(make_model, ftype, B, q4, monkeypatch):
         assert set(rep) == {"embed_ln", "qkv_attention2", "layer_tail", "pool_normalize"}, sorted(rep)
         assert rep["qkv_attention2"]["launches"] == hp.n_layer and rep["layer_tail"]["launches"] == hp.n_layer
     else:
-        assert set(rep) == {"embed_ln", "model_kernel", "pool_normalize"}, sorted(rep)
+        assert set(rep) == {"embed_ln", "model_kernel"}, sorted(rep)
         assert rep["model_kernel"]["launches"] == 1
         m.set_option("one_launch", "0")
         assert np.array_equal(m.eval_packed(ids.reshape(-1), cu), out)          # the same bits as two launches per layer
