@@ -310,7 +310,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
-    else if (key == "one_launch") { one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1; pool_fused_ = value != "3"; }
+    else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
 }
 
@@ -486,7 +486,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                       L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(), L.ln_out_b.as<float>()};
         }
         timed("model_kernel", hp_.n_layer * (2.0 * Td * 3 * H * H + att_flops + 2.0 * Td * H * H + 4.0 * Td * H * I), s, [&] {
-            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, pool_fused_ ? d_out : nullptr, max_len, status_.as<int>(), s);
+            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, d_out, max_len, status_.as<int>(), s);
         });
     }
     for (int il = 0; !skinny && !one_launch && il < hp_.n_layer; ++il) {
@@ -521,7 +521,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         tap(il + 1);
     }
     // (the one-launch kernel's workgroups pool their sentences themselves)
-    if (!one_launch || !pool_fused_) timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, max_len, status_.as<int>(), d_out, s); });
+    if (!one_launch) timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, max_len, status_.as<int>(), d_out, s); });
     (void)I;
     HIP_OK(hipGetLastError(), err, -1);
     HIP_OK(hipEventRecord(busy_, s), err, -1);

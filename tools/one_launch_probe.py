@@ -23,7 +23,7 @@ for dims, ftype in (("minilm-l6", "f16"), ("minilm-l6", "q4_0")):
         out = torch.empty((B, hp.n_embd), dtype=torch.float32, device=dev)
         m.reserve(B * 128, B)
         s = torch.cuda.current_stream(dev)
-        for mode in ("0", "1", "3", "1", "3", "0", "1", "3"):
+        for mode in ("0", "1", "0", "1"):
             m.set_option("one_launch", mode)
             for _ in range(20): m.eval_packed_device(t.data_ptr(), cu.data_ptr(), B, B * 128, 128, out.data_ptr(), s.cuda_stream)
             torch.cuda.synchronize(); t0 = time.perf_counter()
