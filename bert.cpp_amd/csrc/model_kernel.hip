@@ -25,6 +25,15 @@
 
 namespace bert_hip {
 
+#ifdef BERT_HIP_MODEL_TIMELINE      // (tuning aid: tools/variant.sh tl model_kernel.hip "-DBERT_HIP_MODEL_TIMELINE -fno-slp-vectorize")
+// phase boundaries of every workgroup on the constant 100 MHz counter: [0] start, [1 + 2 l] window phase of layer l done, [2 + 2 l] its tail
+// phase done, [1 + 2 L] pooled
+static __device__ unsigned long long g_tl_model[1024 * 32];
+#define MK_STAMP(i) do { const int mk_i = (i); if (threadIdx.x == 0 && mk_i < 32) g_tl_model[(blockIdx.x & 1023) * 32 + mk_i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MK_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int MODEL_MAX_LAYERS = 12;
@@ -76,6 +85,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         asm volatile("" : "+v"(ln), "+s"(w));
         return w * 64 + ln;
     };
+    MK_STAMP(0);
     const int n_layer = rows > 0 ? m.n_layer : 0;    // (a window of empty sentences: nothing to compute, NaN rows from the pooling below)
     for (int l = 0; l < n_layer; ++l) {
         const ModelLayerArgs &L = m.layer[l];
@@ -90,6 +100,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MK_STAMP(1 + 2 * l);
         tid = thread_id();
         {
             TailArgs t;
@@ -101,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        MK_STAMP(2 + 2 * l);
     }
     // ---- mean-pool + L2 normalise of the window's sentences (pool_normalize.h: the pooling kernel's body and bits), while the
     // other workgroups are still in their layers: the rows were written by this workgroup and sit in the L2
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
             __syncthreads();                                  // (the next sentence reuses the partial rows)
         }
     }
+    MK_STAMP(1 + 2 * n_layer);
 }
 
 // full: every sentence exactly 128 tokens (T = 128 B: the specialised form); otherwise windows of whole sentences — the caller's
@@ -145,6 +158,46 @@ void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x
     auto go = [&](auto kernel, int which) {
         configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, m);
+#ifdef BERT_HIP_MODEL_TIMELINE
+        static int shots = 0;
+        if (grid >= 256 && shots++ == 30) {
+            (void)hipDeviceSynchronize();
+            static unsigned long long h[1024 * 32];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl_model), sizeof(h));
+            const int nw = grid < 1024 ? grid : 1024, ns = 2 + 2 * n_layer;
+            unsigned long long t0 = ~0ull;
+            for (int w = 0; w < nw; ++w) t0 = h[w * 32] < t0 ? h[w * 32] : t0;
+            // per stamp: min / mean / max over the workgroups of (stamp - earliest start), in microseconds (100 MHz counter)
+            fprintf(stderr, "model_kernel timeline, %d workgroups (us after the first workgroup's start: min mean max):\n", nw);
+            for (int i = 0; i < ns; ++i) {
+                double lo = 1e30, hi = 0, sum = 0;
+                for (int w = 0; w < nw; ++w) { const double v = (double)(h[w * 32 + i] - t0) * 0.01; lo = v < lo ? v : lo; hi = v > hi ? v : hi; sum += v; }
+                fprintf(stderr, "  stamp %2d: %8.2f %8.2f %8.2f\n", i, lo, sum / nw, hi);
+            }
+            // per phase: mean duration over workgroups
+            fprintf(stderr, "  mean phase durations (window, tail) per layer:");
+            for (int l = 0; l < n_layer; ++l) {
+                double a = 0, b = 0;
+                for (int w = 0; w < nw; ++w) { a += (double)(h[w * 32 + 1 + 2 * l] - h[w * 32 + 2 * l]) * 0.01; b += (double)(h[w * 32 + 2 + 2 * l] - h[w * 32 + 1 + 2 * l]) * 0.01; }
+                fprintf(stderr, " (%.1f, %.1f)", a / nw, b / nw);
+            }
+            fprintf(stderr, "\n  mean end per XCD:");
+            for (int x = 0; x < 8; ++x) {
+                double e = 0; int c = 0;
+                for (int w = x; w < nw; w += 8) { e += (double)(h[w * 32 + ns - 1] - t0) * 0.01; ++c; }
+                fprintf(stderr, " %.1f", e / c);
+            }
+            fprintf(stderr, "\n  mean end per eighth of the grid:");
+            for (int x = 0; x < 8; ++x) {
+                double e = 0; int c = 0;
+                for (int w = x * nw / 8; w < (x + 1) * nw / 8; ++w) { e += (double)(h[w * 32 + ns - 1] - t0) * 0.01; ++c; }
+                fprintf(stderr, " %.1f", e / c);
+            }
+            double pl = 0;
+            for (int w = 0; w < nw; ++w) pl += (double)(h[w * 32 + 1 + 2 * n_layer] - h[w * 32 + 2 * n_layer]) * 0.01;
+            fprintf(stderr, "; pooling %.2f\n", pl / nw);
+        }
+#endif
     };
     if (full) { if (H == 256) go(model_kernel<2, false>, 0); else go(model_kernel<3, false>, 1); }
     else { if (H == 256) go(model_kernel<2, true>, 2); else go(model_kernel<3, true>, 3); }
