@@ -227,7 +227,7 @@ def test_one_launch_on_ragged_windows(make_model, dims, ftype):
     rng = np.random.default_rng(5)
     cases = {"mixed": rng.integers(1, 129, size=300), "ones": np.ones(70, dtype=np.int64), "16s": np.full(40, 16), "17s": np.full(33, 17),
              "two": np.array([128, 3]), "max 64": rng.integers(40, 65, size=50), "32s": np.full(64, 32), "one": np.array([5]),
-             "127s": np.full(9, 127), "many": rng.integers(3, 129, size=2000)}
+             "127s": np.full(9, 127), "128s": np.full(7, 128), "many": rng.integers(3, 129, size=2000)}
     H = hp.n_embd
     for name, lens in cases.items():
         cu = _cu(lens)
