@@ -90,6 +90,9 @@ bool context_devices(std::vector<int> &devs, std::string &err) {
         return false;
     }
     const char *list = getenv("BERT_HIP_DEVICES");
+    // (BERT_HIP_DEVICE=<n>, the single-device spelling of earlier builds: an alias for a list of one)
+    if (!list || !*list) list = getenv("BERT_HIP_DEVICE");
+    if (list && !*list) list = nullptr;
     devs.clear();
     if (list && *list && strcmp(list, "all") != 0) {
         for (const char *p = list; *p;) {
@@ -486,7 +489,20 @@ int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *t
                 if (!ctx->gathered[0]->ensure((size_t)n_sentences * H * 4, err)) { fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str()); return -3; }
                 dst[0] = ctx->gathered[0]->as<float>();
             }
-            if (!ctx->rccl.init(devs, err) || !ctx->rccl.all_gather(src.data(), dst.data(), bounds, H, streams.data(), err)) {
+            bool ok = ctx->rccl.init(devs, err);
+            if (ok && ctx->workers && ctx->workers->n_threads() == n_dev - 1) {
+                // every device's call from the host thread that serves the device (worker d - 1, the caller for device 0)
+                std::vector<int> each((size_t)n_dev + 1);
+                for (int d = 0; d <= n_dev; ++d) each[d] = d;
+                std::vector<std::string> errs((size_t)n_dev);
+                const int rc = ctx->workers->run(each, [&](int d, int, int) {
+                    return ctx->rccl.exchange_on(d, src[d], dst[d], bounds, H, streams[d], errs[d]) ? 0 : -3; }, &err);
+                for (auto &e : errs) if (err.empty() && !e.empty()) err = e;
+                ok = rc == 0;
+            } else if (ok) {
+                ok = ctx->rccl.all_gather(src.data(), dst.data(), bounds, H, streams.data(), err);
+            }
+            if (!ok) {
                 fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
                 return -3;
             }

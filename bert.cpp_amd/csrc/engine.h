@@ -120,9 +120,13 @@ private:
     // profiling
     bool profiling_ = false;
     std::vector<hipEvent_t> ev_pool_;
-    struct Pending { const char *name; hipEvent_t a, b; double flops; };
+    struct Pending { const char *name; hipEvent_t a, b; double flops; int launches; };
+    std::string replay_name_;         // "profile_replay": time K repeats of this kernel between one event pair (engine.hip timed())
+    int replay_k_ = 10;
+    bool replay_done_ = false;
     std::vector<Pending> pending_;
     std::map<std::string, KernelStat> stats_;
+    std::map<std::string, int> families_;       // profile: mat-mul launches per kernel family ("family:gemm256_q4" ...)
 };
 
 }  // namespace bert_hip

@@ -1,5 +1,7 @@
 // gemm256.hip — the large-tile weight mat-mul of the H > 384 models (bert-base / mpnet dimensions, BASELINE configs 3, 4):
-//   C[t][n] = epilogue( sum_k A[t][k] * W[n][k] + bias[n] )        A: f16 activations, W: f16 (q4 matrices are expanded at load)
+//   C[t][n] = epilogue( sum_k A[t][k] * W[n][k] + bias[n] )        A: f16 activations, W: f16 image, or q4_0 / q4_1 planes
+//   (BERT_HIP_Q4=fused: the matrix stays 4-bit in HBM / L2 and its blocks are dequantised into the weight tile's LDS image by
+//   the tile load itself — same image, same MFMA sequence, same bits as the f16 form on the expanded matrix)
 // Same operation and epilogues as gemm.hip (reference bert.cpp:822-839, :859-865, :878-882, :885-891); what changes is the
 // shape of the work, chosen for the two things a power-limited MI355X pays for besides the MFMAs themselves — LDS
 // fragment reads and L2 -> LDS tile traffic:
@@ -50,6 +52,8 @@ struct Gemm256Args {
     const float *bias;      // [N]
     const half_t *resid;    // [M_pad][N] or null
     half_t *C;              // [M_pad][N]
+    const uint4 *qs;        // q4 forms: nibble plane / scale plane of W (kernels.h GemmWeight), w16 unused
+    const void *sc;
     int N, K, n_tiles_n, n_tiles;
     int n_groups;           // feature-tile groups an XCD pair / quad shares the walk with (1: every XCD walks all feature tiles)
 };
@@ -111,9 +115,17 @@ __device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
 // tiles without a gap: the first reduction tile of the next output tile is requested during the last one of the current,
 // and the epilogue of a finished output tile runs after the NEXT tile's first barrier — its global stores are then
 // retired under a whole reduction tile of MFMAs instead of in front of a barrier.
-template <int EPI>
+// WT != GW_F16 (q4_0 / q4_1 planes): the weight half of a reduction tile is 512 blocks of 32 weights, one per thread.  A
+// thread REQUESTS its block of the tile after next (16 bytes of nibbles + the scale: two plain global loads, coalesced —
+// a wave's 64 blocks are 1 KiB + 128 / 256 B of the tile-contiguous planes) in the last k-step of a reduction tile and EXPANDS
+// it one tile later, a 16-byte chunk at a time behind MFMAs of the first two k-steps (v_perm_b32 builds (1024 + q) half pairs,
+// packed f16 math applies (q - 8) d or q d + m: ~15 VALU + one ds_write_b128 per chunk), into the stage the f16 form fills by
+// LDS-DMA — the activation half still arrives that way.  At an output-tile boundary the pending block is expanded in one go in
+// front of the finished tile's epilogue, so the raw registers are dead while the epilogue needs every register.
+template <int EPI, int WT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool Q4 = WT != GW_F16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,7 +164,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     }
     auto dma_piece = [&](const half_t *src, char *stage_base, auto i_tag) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;       // 0..3: activation pieces, 4..7: weight pieces
-        __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + doff[i & 3]), G2_LDS(stage_base + (i >> 2) * G2_TILE + (wave * 4 + (i & 3)) * 1024), 16, 0, 0);
+        if constexpr (Q4 && i >= 4) return;             // (q4: the weight half is expanded from blocks, below)
+        else __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + doff[i & 3]), G2_LDS(stage_base + (i >> 2) * G2_TILE + (wave * 4 + (i & 3)) * 1024), 16, 0, 0);
     };
 
     // ---- fragment addresses of the four k-steps of a reduction tile (stage 0; the other stage is address ^ 64 KiB)
@@ -171,6 +184,60 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         f.a[0] = g2_read_b128<0>(aW[kk]); f.a[1] = g2_read_b128<4096>(aW[kk]);
         f.a[2] = g2_read_b128<8192>(aW[kk]); f.a[3] = g2_read_b128<12288>(aW[kk]);
         f.b[0] = g2_read_b128<0>(aA[kk]); f.b[1] = g2_read_b128<4096>(aA[kk]);
+    };
+
+    // ---- q4: this thread's block of a weight tile.  A wave owns 32 rows x 2 blocks; its lanes are dealt so that the eight lanes
+    // of a ds_write_b128 group (8 x 8 contiguous lanes) hit eight different 16-byte columns of the swizzled tile:
+    // lane = 8 g + j -> row 2 (j & 3) + (g & 1) + 8 (g >> 1), block j >> 2.
+    const int q_row = wave * 32 + 2 * (lane & 3) + ((lane >> 3) & 1) + 8 * (lane >> 4), q_kb = (lane >> 2) & 1;
+    unsigned q_dst = (unsigned)(size_t)smem + (unsigned)(G2_TILE + q_row * 128 + (((q_kb * 4) ^ ((q_row >> 1) & 7)) << 4));   // chunk c: ^ (c << 4)
+    int q_lane_idx = (q_row & 31) * 2 + q_kb;   // within the wave's 64 consecutive blocks of the planes
+    // The request is hand-issued (two asm global loads, scalar base + lane offset): a compiler-visible load is retired by the
+    // compiler with a vmcnt that also covers the activation pieces issued behind it — a wait for LDS-DMA in front of the first
+    // chunk.  Every path from a request to its expansion crosses a reduction-tile barrier (vmcnt(0)), which names these registers.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 raw_q = {};
+    unsigned raw_sc = 0;
+    unsigned q_voff = (unsigned)q_lane_idx;
+    auto q4_request = [&](int n0_, int kt_) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            // planes: 128-row tiles of 256 blocks, tile (n / 128, kt) at ((n / 128) nk + kt) * 256; this wave: rows 32 (wave & 3) ..
+            const size_t wave_base = ((size_t)((n0_ >> 7) + (wave >> 2)) * nk + kt_) * 256 + (size_t)(wave & 3) * 64;
+            const uint4 *qb = p.qs + wave_base;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(raw_q) : "v"(q_voff << 4), "s"(qb) : "memory");
+            if constexpr (WT == GW_Q4_0) {
+                const unsigned short *sb = (const unsigned short *)p.sc + wave_base;
+                asm volatile("global_load_ushort %0, %1, %2" : "=v"(raw_sc) : "v"(q_voff << 1), "s"(sb) : "memory");
+            } else {
+                const unsigned *sb = (const unsigned *)p.sc + wave_base;
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(raw_sc) : "v"(q_voff << 2), "s"(sb) : "memory");
+            }
+        }
+    };
+    // the requested block has landed (behind a vmcnt(0)): hand it to the compiler as the expansion's input
+    auto q4_raw = [&]() __attribute__((always_inline)) {
+        RawBlock r;
+        r.q = make_uint4(raw_q[0], raw_q[1], raw_q[2], raw_q[3]);
+        r.sc = raw_sc;
+        return r;
+    };
+    auto tile_barrier = [&](G2Frag &f) __attribute__((always_inline)) {
+        if constexpr (Q4)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"
+                         : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(raw_q), "+v"(raw_sc) : : "memory");
+        else g2_tile_barrier(f);
+    };
+    auto q4_expand_one = [&](unsigned stage_xor, auto c_tag) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            constexpr int c = decltype(c_tag)::value;
+            const uint4 v = q4_expand_chunk<WT>(q4_raw(), c);
+            const unsigned dst = (q_dst ^ stage_xor) ^ (unsigned)(c << 4);
+            const u32x4 vv = {v.x, v.y, v.z, v.w};
+            asm volatile("ds_write_b128 %0, %1" : : "v"(dst), "v"(vv) : "memory");
+        }
+    };
+    auto q4_expand_all = [&](unsigned stage_xor) __attribute__((always_inline)) {
+        static_for<4>([&](auto c) __attribute__((always_inline)) { q4_expand_one(stage_xor, c); });
     };
 
     f32x16 acc[4][2];                                 // [feature block][token block]
@@ -345,6 +412,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
         dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
         dma_piece(w, smem, I4{}); dma_piece(w, smem, I5{}); dma_piece(w, smem, I6{}); dma_piece(w, smem, I7{});
+        if constexpr (Q4) {
+            q4_request(n0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_q), "+v"(raw_sc) : : "memory");
+            q4_expand_all(0u);
+            q4_request(n0, 1);
+        }      // (raw: always the tile after the one being multiplied)
     }
     init_loads(m0, n0);                                // (the first tile's initial values: one exposed round trip per launch)
     init_acc();
@@ -358,13 +431,25 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         constexpr int piece = g2_piece_at(decltype(step_tag)::value, decltype(m_tag)::value);
         if constexpr (piece >= 0) dma_piece(piece < 4 ? na : nw, nstage, std::integral_constant<int, (piece >= 0 ? piece : 0)>{});
     };
-    auto steps_0_to_2 = [&](const half_t *na, const half_t *nw, char *nstage) __attribute__((always_inline)) {
+    // q4 (`expand`: the pending block has not been expanded in one go at the top of the period): chunks 0, 1 behind MFMAs 1, 5
+    // of k-step 0, chunks 2, 3 behind MFMAs 1, 5 of k-step 1; the block of the tile after next (rn0, rkt) is requested behind
+    // MFMA 1 of k-step 2, into the registers chunk 3 has just released.
+    auto q4_fill = [&](auto expand_tag, unsigned nxor, int rn0, int rkt, auto step_tag, auto m_tag) __attribute__((always_inline)) {
+        if constexpr (Q4) {
+            constexpr int step = decltype(step_tag)::value, m = decltype(m_tag)::value;
+            if constexpr (decltype(expand_tag)::value && step <= 2 && (m == 1 || m == 5))
+                q4_expand_one(nxor, std::integral_constant<int, (step - 1) * 2 + (m == 5 ? 1 : 0)>{});
+            if constexpr (step == 3 && m == 1) q4_request(rn0, rkt);
+        }
+    };
+    auto steps_0_to_2 = [&](const half_t *na, const half_t *nw, char *nstage, auto expand_tag, int rn0, int rkt) __attribute__((always_inline)) {
+        const unsigned nxor = (unsigned)(nstage - smem);
         read_frag(f1, I1{}); g2_wait6(f0);
-        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I1{}, m); });
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I1{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I1{}, m); });
         read_frag(f0, I2{}); g2_wait6(f1);
-        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I2{}, m); });
+        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I2{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I2{}, m); });
         read_frag(f1, I3{}); g2_wait6(f0);
-        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I3{}, m); });
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I3{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I3{}, m); });
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { aA[kk] ^= (unsigned)G2_STAGE; aW[kk] ^= (unsigned)G2_STAGE; }
     };
@@ -377,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         const int nm0 = more ? (next / cnt_n) * G2_BM : m0, nn0 = more ? (n_begin + next % cnt_n) * G2_BN : n0;
         const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
         {   // ---- reduction tile 0: the previous output tile is finished behind its barrier
-            g2_tile_barrier(f1);
+            tile_barrier(f1);
             const half_t *na = ta + G2_BK, *nw = tw + G2_BK;
             char *nstage = smem + (stage ^ 1) * G2_STAGE;
             // (this tile's step-0 pieces go out in one go: with a previous output tile its last k-step and epilogue follow,
@@ -386,17 +471,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                 constexpr int piece = decltype(i)::value;
                 dma_piece(piece < 4 ? na : nw, nstage, i);
             });
+            // (q4: this output tile's second weight tile, in one go — its registers must be free during the epilogue)
+            if constexpr (Q4) q4_expand_all((unsigned)(nstage - smem));
             if (have_prev) {
                 mfma_step(f1);                         // the last k-step of the previous output tile
                 epilogue(pm0, pn0, true, m0, n0);
                 init_acc();
             }
             read_frag(f0, I0{});
-            steps_0_to_2(na, nw, nstage);
+            steps_0_to_2(na, nw, nstage, std::false_type{}, nk > 2 ? n0 : nn0, nk > 2 ? 2 : 0);
             stage ^= 1;
         }
         for (int kt = 1; kt < nk; ++kt) {
-            g2_tile_barrier(f1);
+            tile_barrier(f1);
             // the next reduction tile (of this output tile, or the first of the next one) into the stage just released
             const bool last = kt + 1 == nk;
             const half_t *na = last ? p.A + (size_t)nm0 * K : ta + (kt + 1) * G2_BK;
@@ -405,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             read_frag(f0, I0{});
             // the previous reduction tile's last k-step, with the new tile's first requests between its MFMAs
             mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I0{}, m); });
-            steps_0_to_2(na, nw, nstage);
+            steps_0_to_2(na, nw, nstage, std::true_type{}, kt + 2 < nk ? n0 : nn0, kt + 2 < nk ? kt + 2 : kt + 2 - nk);
             stage ^= 1;
         }
         have_prev = true; pm0 = m0; pn0 = n0;
@@ -413,26 +500,27 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         tile = next; m0 = nm0; n0 = nn0;
     }
     // the request issued behind the last output tile must not outlive the workgroup
-    g2_tile_barrier(f1);
+    tile_barrier(f1);
     mfma_step(f1);
     epilogue(pm0, pn0, false, 0, 0);
 }
 
 bool gemm256_supported(const GemmWeight &W, int M_pad) {
-    return W.type == GW_F16 && W.w16 && W.N % G2_BN == 0 && W.K % G2_BK == 0 && W.K >= 2 * G2_BK && M_pad % G2_BM == 0 && M_pad > 0;
+    return (W.type == GW_F16 ? W.w16 != nullptr : W.qs != nullptr && W.sc != nullptr) && W.N % G2_BN == 0 && W.K % G2_BK == 0 && W.K >= 2 * G2_BK && M_pad % G2_BM == 0 && M_pad > 0;
 }
 
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
                     int epilogue, hipStream_t stream) {
     Gemm256Args a;
-    a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C;
+    a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C; a.qs = W.qs; a.sc = W.sc;
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
     a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
     // feature groups: only where W (N x K f16) overflows an XCD's L2 share and reading the activations twice is the cheaper
     // side (K small against N), with enough token tiles for the 8 / G token ranges to balance
     // (measured, bert-base / mpnet dimensions: up-projection -2.5 %; FETCH_SIZE per launch in profiles/)
     a.n_groups = 1;
-    if ((size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G2_BM >= 64) a.n_groups = 2;
+    // (a q4 matrix is 9 / 32 or 10 / 32 of that: the up-projection's 1.3 MiB stay resident beside everything else)
+    if (W.type == GW_F16 && (size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G2_BM >= 64) a.n_groups = 2;
     // one persistent workgroup per CU (256 on an MI355X, a multiple of the 8 XCDs), fewer when there are fewer tiles
     static int n_cu[MAX_HIP_DEVICES] = {};
     int dev = 0;
@@ -444,15 +532,23 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
     const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
-    static DeviceFlags configured[3];
+    static DeviceFlags configured[9];
     auto go = [&](auto kernel, int e) {
         configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
+    auto by_type = [&](auto epi_tag) {
+        constexpr int E = decltype(epi_tag)::value;
+        switch (W.type) {
+            case GW_F16: go(gemm256_kernel<E, GW_F16>, E); break;
+            case GW_Q4_0: go(gemm256_kernel<E, GW_Q4_0>, 3 + E); break;
+            default: go(gemm256_kernel<E, GW_Q4_1>, 6 + E); break;
+        }
+    };
     switch (epilogue) {
-        case EPI_BIAS: go(gemm256_kernel<EPI_BIAS>, 0); break;
-        case EPI_BIAS_GELU: go(gemm256_kernel<EPI_BIAS_GELU>, 1); break;
-        default: go(gemm256_kernel<EPI_BIAS_RESID>, 2); break;
+        case EPI_BIAS: by_type(std::integral_constant<int, EPI_BIAS>{}); break;
+        case EPI_BIAS_GELU: by_type(std::integral_constant<int, EPI_BIAS_GELU>{}); break;
+        default: by_type(std::integral_constant<int, EPI_BIAS_RESID>{}); break;
     }
 }
 

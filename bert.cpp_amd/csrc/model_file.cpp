@@ -185,9 +185,10 @@ bool ModelFile::load(const char *fname, bool vocab_only, std::string &err) {
                     float v;
                     memcpy(&v, src + 4 * k, 4);
                     const _Float16 h = (_Float16)v;
-                    // (a finite scale outside f16's range would silently become inf or 0: refuse the file instead)
+                    // (a finite scale above f16's range would silently become inf: refuse the file instead.  A scale below
+                    // f16's smallest subnormal flushes to zero — the block's values change by less than 2.4e-7 — and loads)
                     const float back = (float)h;
-                    if (std::isfinite(v) && (!std::isfinite(back) || (v != 0.f && back == 0.f))) {
+                    if (std::isfinite(v) && !std::isfinite(back)) {
                         err = "tensor '" + name + "': a legacy q4 block scale (" + std::to_string(v) + ") does not fit f16";
                         return false;
                     }

@@ -10,9 +10,14 @@
 // through every layer — window-kernel phase (Q|K|V projection + attention), layer-tail phase (out-projection + LN + FFN + LN),
 // the two kernels' bodies unchanged (same arithmetic, same bits: tested) — and nothing ever puts the workgroups back in step.
 // The hand-overs (ctx from the attention waves to the tail, x from the tail to the next layer's projection waves) are plain
-// global stores and loads of the SAME workgroup: 96 KiB each, written and read back through the CU's L1 / the XCD's L2 behind a
-// workgroup-scope fence (one L1 per CU, shared by the workgroup's waves: no invalidate needed outside threadgroup-split
-// mode), so the per-layer load bursts leave the HBM.
+// global stores and loads of the SAME workgroup: 96 KiB each, behind a workgroup-scope fence (one L1 per CU, shared by the
+// workgroup's waves: no invalidate needed outside threadgroup-split mode).  They do NOT stay inside the XCD's L2: 256
+// workgroups x 192 KiB = 48 MiB per layer against 32 MiB of L2, and every store leaves the L2 towards the fabric anyway —
+// measured 313 MB written and 1.06 GB of fabric traffic per launch (profiles/r3_pmc.txt), absorbed by the Infinity Cache at
+// about 1.3 TB/s: far from a limit, but not free.  What the single launch removes is the lockstep, not the bytes.
+// Full form only: the kernel trusts n_tokens = 128 n_sentences to mean "every sentence is exactly 128 tokens"; that holds
+// whenever the caller's max_len promise (<= 128) does.  A batch that breaks it is flagged by the pooling guard (status word),
+// and the rows of sentences sharing a 128-token block with the offender are not meaningful (include/bert_hip.h).
 //
 // Both bodies keep their own LDS layout (160 KiB each, used one after the other) and register budget (256 per wave).  This
 // translation unit is compiled with the flags of both (Makefile): -fno-slp-vectorize (qkv_attention2) and

@@ -148,9 +148,10 @@ typedef int (*fn_comm_init_all)(void **comms, int ndev, const int *devlist);
 typedef int (*fn_comm_destroy)(void *comm);
 typedef int (*fn_group)(void);
 typedef int (*fn_broadcast)(const void *send, void *recv, size_t count, int dtype, int root, void *comm, hipStream_t s);
+typedef int (*fn_allgather)(const void *send, void *recv, size_t sendcount, int dtype, void *comm, hipStream_t s);
 typedef const char *(*fn_err)(int);
 constexpr int NCCL_FLOAT32 = 7;
-enum { F_INIT, F_DESTROY, F_GSTART, F_GEND, F_BCAST, F_ERR };
+enum { F_INIT, F_DESTROY, F_GSTART, F_GEND, F_BCAST, F_ERR, F_ALLGATHER };
 }  // namespace
 
 RcclGather::~RcclGather() {
@@ -175,8 +176,8 @@ bool RcclGather::init(const std::vector<int> &devices, std::string &err) {
         if (lib_) break;
     }
     if (!lib_) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
-    const char *names[] = {"ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclBroadcast", "ncclGetErrorString"};
-    for (int i = 0; i < 6; ++i) {
+    const char *names[] = {"ncclCommInitAll", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd", "ncclBroadcast", "ncclGetErrorString", "ncclAllGather"};
+    for (int i = 0; i < 7; ++i) {
         fn_[i] = dlsym(lib_, names[i]);
         if (!fn_[i]) { err = std::string("librccl.so lacks ") + names[i]; return fail(); }
     }
@@ -190,22 +191,58 @@ bool RcclGather::init(const std::vector<int> &devices, std::string &err) {
     return true;
 }
 
+bool RcclGather::equal_shards(const std::vector<int> &bounds) {
+    const int n = (int)bounds.size() - 1;
+    if (n < 1 || bounds[1] - bounds[0] <= 0) return false;
+    for (int r = 1; r < n; ++r)
+        if (bounds[r + 1] - bounds[r] != bounds[1] - bounds[0]) return false;
+    return true;
+}
+
+// rank d's part of the exchange, on the calling thread's current device (the caller has selected devices_[d]).  Equal shards
+// (every BASELINE config: fixed-length batches cut by token count): ONE ncclAllGather — rank r's shard lands at row
+// bounds[r] = r * count of every device's matrix.  Unequal shards: a broadcast per shard, grouped (non-roots pass their own
+// destination as the unused send buffer: a null pointer does not survive NCCL_CHECK_POINTERS).
+int RcclGather::issue(int d, const float *src, float *dst, const std::vector<int> &bounds, int H, hipStream_t stream, bool grouped) {
+    const int n = (int)comms_.size();
+    if (equal_shards(bounds))
+        return ((fn_allgather)fn_[F_ALLGATHER])(src, dst, (size_t)(bounds[1] - bounds[0]) * H, NCCL_FLOAT32, comms_[d], stream);
+    int rc = grouped ? ((fn_group)fn_[F_GSTART])() : 0;
+    for (int root = 0; rc == 0 && root < n; ++root) {
+        const size_t count = (size_t)(bounds[root + 1] - bounds[root]) * H;
+        if (!count) continue;
+        float *slot = dst + (size_t)bounds[root] * H;
+        rc = ((fn_broadcast)fn_[F_BCAST])(d == root ? src : slot, slot, count, NCCL_FLOAT32, root, comms_[d], stream);
+    }
+    if (grouped) {
+        const int rc2 = ((fn_group)fn_[F_GEND])();
+        if (rc == 0) rc = rc2;
+    }
+    return rc;
+}
+
 bool RcclGather::all_gather(float *const *src, float *const *dst, const std::vector<int> &bounds, int H, hipStream_t *streams,
                             std::string &err) {
     const int n = (int)comms_.size();
     if ((int)bounds.size() != n + 1) { err = "RcclGather: shard count does not match the communicator"; return false; }
+    // one host thread drives every device's communicator: the calls of the n ranks form ONE group
     int rc = ((fn_group)fn_[F_GSTART])();
-    for (int root = 0; rc == 0 && root < n; ++root) {
-        const size_t count = (size_t)(bounds[root + 1] - bounds[root]) * H;
-        if (!count) continue;
-        for (int d = 0; rc == 0 && d < n; ++d) {
-            (void)hipSetDevice(devices_[d]);
-            rc = ((fn_broadcast)fn_[F_BCAST])(d == root ? src[root] : nullptr, dst[d] + (size_t)bounds[root] * H, count, NCCL_FLOAT32,
-                                             root, comms_[d], streams[d]);
-        }
+    for (int d = 0; rc == 0 && d < n; ++d) {
+        if (hipSetDevice(devices_[d]) != hipSuccess) { rc = -1; break; }
+        rc = issue(d, src[d], dst[d], bounds, H, streams[d], false);
     }
     const int rc2 = ((fn_group)fn_[F_GEND])();
     if (rc == 0) rc = rc2;
+    if (rc != 0) { err = rc < 0 ? std::string("RCCL exchange: hipSetDevice failed") : std::string("RCCL exchange: ") + ((fn_err)fn_[F_ERR])(rc); return false; }
+    return true;
+}
+
+bool RcclGather::exchange_on(int d, const float *src, float *dst, const std::vector<int> &bounds, int H, hipStream_t stream,
+                             std::string &err) {
+    const int n = (int)comms_.size();
+    if ((int)bounds.size() != n + 1 || d < 0 || d >= n) { err = "RcclGather: shard count does not match the communicator"; return false; }
+    if (hipSetDevice(devices_[d]) != hipSuccess) { err = "RCCL exchange: hipSetDevice failed"; return false; }
+    const int rc = issue(d, src, dst, bounds, H, stream, true);
     if (rc != 0) { err = std::string("RCCL exchange: ") + ((fn_err)fn_[F_ERR])(rc); return false; }
     return true;
 }

@@ -48,12 +48,18 @@ public:
     ~RcclGather();
     bool init(const std::vector<int> &devices, std::string &err);
     bool ready() const { return !comms_.empty(); }
-    // src[r]: shard r on device r ((bounds[r+1] - bounds[r]) * H floats); dst[d]: [n_sentences][H] on device d.  One
-    // grouped exchange (a broadcast per shard: the shards differ in size) on the devices' streams; not synchronised.
+    // src[r]: shard r on device r ((bounds[r+1] - bounds[r]) * H floats); dst[d]: [n_sentences][H] on device d.  The path's
+    // ONE exchange step, on the devices' streams, not synchronised: one ncclAllGather per device when the shards are equal
+    // (every fixed-length batch), a grouped broadcast per shard otherwise.
+    // all_gather: every device's call issued by the calling thread (one group); exchange_on: device d's call only, to be
+    // issued by the host thread that serves device d (ShardWorkers) — the n threads' calls meet inside RCCL.
     bool all_gather(float *const *src, float *const *dst, const std::vector<int> &bounds, int H, hipStream_t *streams,
                     std::string &err);
+    bool exchange_on(int d, const float *src, float *dst, const std::vector<int> &bounds, int H, hipStream_t stream, std::string &err);
+    static bool equal_shards(const std::vector<int> &bounds);
 
 private:
+    int issue(int d, const float *src, float *dst, const std::vector<int> &bounds, int H, hipStream_t stream, bool grouped);
     void *lib_ = nullptr;
     std::vector<void *> comms_;
     std::vector<int> devices_;

@@ -152,6 +152,44 @@ __device__ __forceinline__ void q4_expand_block(const RawBlock &r, ChunkPtr chun
         }
 }
 
+// One 16-byte chunk (eight weights, plain k order: elements 8 c .. 8 c + 7 of the block) of a q4 block, the arithmetic of
+// q4_expand_block: for kernels that spread a block's expansion over several issue gaps (gemm256.hip).
+template <int WT>
+__device__ __forceinline__ uint4 q4_expand_chunk(const RawBlock &r, int c) {
+    f16x2 d2, m2;
+    if (WT == GW_Q4_0) {
+        const _Float16 d = __builtin_bit_cast(_Float16, (unsigned short)(r.sc & 0xffffu));
+        d2 = (f16x2){d, d};
+        m2 = (f16x2){(_Float16)0, (_Float16)0};
+    } else {
+        const f16x2 dm = __builtin_bit_cast(f16x2, r.sc);
+        d2 = (f16x2){dm[0], dm[0]};
+        m2 = (f16x2){dm[1], dm[1]};
+    }
+    unsigned magic, sel01, sel23, offb;
+    asm volatile("v_mov_b32 %0, 0x64646464" : "=v"(magic));
+    asm volatile("s_mov_b32 %0, 0x04010400" : "=s"(sel01));
+    asm volatile("s_mov_b32 %0, 0x04030402" : "=s"(sel23));
+    if (WT == GW_Q4_0) asm volatile("s_mov_b32 %0, 0x64086408" : "=s"(offb));      // 1032, 1032
+    else asm volatile("s_mov_b32 %0, 0x64006400" : "=s"(offb));                    // 1024, 1024
+    const f16x2 off = __builtin_bit_cast(f16x2, offb);
+    auto four = [&](unsigned word, bool high, unsigned &o0, unsigned &o1) __attribute__((always_inline)) {
+        const unsigned n4 = (high ? (word >> 4) : word) & 0x0f0f0f0fu;
+        f16x2 v0 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(magic, n4, sel01)) - off;
+        f16x2 v1 = __builtin_bit_cast(f16x2, __builtin_amdgcn_perm(magic, n4, sel23)) - off;
+        if (WT == GW_Q4_0) { v0 = v0 * d2; v1 = v1 * d2; }
+        else { v0 = __builtin_elementwise_fma(v0, d2, m2); v1 = __builtin_elementwise_fma(v1, d2, m2); }   // (one rounding: engine.hip row_to_f16)
+        o0 = __builtin_bit_cast(unsigned, v0);
+        o1 = __builtin_bit_cast(unsigned, v1);
+    };
+    const bool high = c >= 2;
+    const unsigned w0 = (c & 1) ? r.q.z : r.q.x, w1 = (c & 1) ? r.q.w : r.q.y;
+    uint4 out;
+    four(w0, high, out.x, out.y);
+    four(w1, high, out.z, out.w);
+    return out;
+}
+
 // LayerNorm of one token's row from f32 values, the way layer_tail.hip's lanes and wave pairs do it (the latency route:
 // skinny.hip, and the per-head form of qkv_attention2.hip): lane = (token l31, half hi) holds the
 // 4-feature runs (n, g) = features 32 n + 8 g + 4 hi .. + 3 of its token (H / 2 values, loaded 16 bytes at a time).

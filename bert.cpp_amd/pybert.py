@@ -349,13 +349,16 @@ class BertModel:
     def profile(self, on: bool) -> None:
         self.lib.bert_hip_profile_enable(self.ctx, int(on))
 
-    def profile_report(self) -> dict:
+    def profile_report(self, families: bool = False) -> dict:
+        """{kernel: {launches, total_ms, flops_per_launch}}; families=True adds the "family:<kernel>_<weights>" lines (which
+        mat-mul kernel served the launches: gemm256_f16 / gemm256_q4 / gemm_mfma_f16 / gemm_mfma_q4 / gemm_naive)."""
         buf = C.create_string_buffer(1 << 16)
         self.lib.bert_hip_profile_report(self.ctx, buf, len(buf))
         out = {}
         for line in buf.value.decode().splitlines():
             name, launches, ms, flops = line.split()
-            out[name] = {"launches": int(launches), "total_ms": float(ms), "flops_per_launch": float(flops)}
+            if families or not name.startswith("family:"):
+                out[name] = {"launches": int(launches), "total_ms": float(ms), "flops_per_launch": float(flops)}
         return out
 
     def set_option(self, key: str, value: str) -> None:

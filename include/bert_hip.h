@@ -67,7 +67,10 @@ BERT_API int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vo
  *   - the workspace grows on demand, and growing allocates (synchronises the device, illegal under stream capture):
  *     call bert_hip_reserve once with the largest batch first;
  *   - lengths are validated on the device: a sentence longer than max_len (or empty) yields a NaN embedding and sets a
- *     status word that bert_hip_check returns (and clears) after synchronising;
+ *     status word that bert_hip_check returns (and clears) after synchronising.  When the status word is set, only the
+ *     rows of sentences that kept the promise AND do not share a 128-token block of the packed batch with an offender are
+ *     meaningful: a batch shaped like full windows (n_tokens_total = 128 n_sentences, max_len = 128) is evaluated block by
+ *     block, and an over-long sentence shifts its neighbours across block boundaries;
  *   - short sentences are packed several to a 128-slot attention window by a kernel of the pass itself (the lengths
  *     exist only in HBM here): results are the bits of the host entry points.                                        */
 BERT_API int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens,
@@ -88,7 +91,12 @@ BERT_API int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id 
  * the forward pass is bracketed by events (this serialises nothing but adds event overhead, so
  * never enable it inside a throughput measurement).  bert_hip_profile_report writes one line per
  * kernel: "<name> <launches> <total_ms> <flops_per_launch_avg>\n" and returns the number of bytes
- * it needed (excluding NUL); it synchronises the device first and resets the counters.          */
+ * it needed (excluding NUL); it synchronises the device first and resets the counters.  Behind the kernels it lists which
+ * mat-mul kernel family served the weight GEMMs of the pass: "family:gemm256_f16" / "family:gemm256_q4" (256 x 256 tiles, f16
+ * image / 4-bit planes dequantised in the tile load), "family:gemm_mfma_f16" / "_q4" (128 x 128 tiles), "family:gemm_naive",
+ * each "<name> <launches> 0 0".  With bert_hip_set_option("profile_replay", "<kernel>:<K>") a pass runs untimed and the
+ * first launch of <kernel> is followed by K repeats of itself between ONE event pair (the pair's cost spread over K launches;
+ * in-place kernels then run on their own output: such a pass's results are not to be used); "" restores a pair per launch. */
 BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
 BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
 
@@ -108,7 +116,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
- * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "chunk_tokens" = n.                                         */
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "chunk_tokens" = n, "profile_replay" (above).                                         */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);
