@@ -63,8 +63,22 @@ CONFIGS = {
     22: dict(name="all-MiniLM-L6-v2 q4_0, batch=1024 seq_len=128 (q4 matrices expanded to f16 at load: engine default)",
              dims="minilm-l6", ftype="q4_0", batch=1024, seq_len=128, key="config2_expanded"),
     3: dict(name="bert-base-uncased q4_1, batch=512 seq_len=512", dims="bert-base", ftype="q4_1", batch=512, seq_len=512),
+    # configs[3] / [4] with the weights 4-bit in HBM (north_star: "q4 block dequant fused into the GEMM tile load"): gemm256's q4 loader
+    33: dict(name="bert-base-uncased q4_1, batch=512 seq_len=512 (4-bit planes in HBM, dequantised in gemm256's tile load)", dims="bert-base",
+             ftype="q4_1", batch=512, seq_len=512, env={"BERT_HIP_Q4": "fused"}, key="config3_fused"),
     4: dict(name="mpnet-base dims (BERT arch) q4_0, seq_len=128, 8192-sentence steps", dims="mpnet-dims", ftype="q4_0",
             batch=8192, seq_len=128),
+    42: dict(name="mpnet-base dims (BERT arch) q4_0, seq_len=128, 8192-sentence steps (4-bit planes in HBM, dequantised in gemm256's tile load)",
+             dims="mpnet-dims", ftype="q4_0", batch=8192, seq_len=128, env={"BERT_HIP_Q4": "fused"}, key="config4_fused"),
+    # BASELINE configs[4] as SURVEY.md §8(d) writes it ("Config 5"): 1,000,000 sentences over 8 GPUs = 125,000 per GPU.  ONE GPU's
+    # share through ONE host-to-host call (ids in host memory -> embeddings in host memory: 61 chunks through the two-slot staging
+    # pipeline, 64 MB in, 384 MB out), cosine on a fixed 256-sentence sample; 45: the same call through the gather entry point
+    # (results stay in HBM, the path's RCCL exchange step runs on a 1-rank communicator)
+    44: dict(name="mpnet-base dims (BERT arch) q4_0: one GPU's share of 1M sentences, ONE host-to-host call of 125,000 x 128 tokens",
+             dims="mpnet-dims", ftype="q4_0", batch=125000, seq_len=128, key="config4_share", host_step=True, share=True),
+    45: dict(name="mpnet-base dims (BERT arch) q4_0: one GPU's share of 1M sentences, ONE bert_hip_eval_packed_gather call of 125,000 x 128 tokens "
+                  "(device-resident result + RCCL exchange step, 1 rank)", dims="mpnet-dims", ftype="q4_0", batch=125000, seq_len=128,
+             key="config4_share_gather", gather_step=True, share=True),
     # not a BASELINE config: sentence lengths like real text (reference examples/sample_client_texts.txt: ~22 words per line)
     # 5: inputs resident in HBM like every other config (the engine packs the sentences into the 128-slot windows of the fused
     # attention kernel with a kernel of its own); 55: the same batch host to host through bert_hip_eval_packed
@@ -141,19 +155,28 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     B, H = cfg["batch"], hp.n_embd
     flat, cu, max_len = config_inputs(cfg, cfg_id, hp, rank)
     T = int(cu[-1])
-    d_tokens = torch.from_numpy(flat).to(device)
-    d_cu = torch.from_numpy(cu).to(device)
-    d_out = torch.empty((B, H), dtype=torch.float32, device=device)
+    host_side = cfg.get("host_step") or cfg.get("gather_step")       # ids start in host memory: the engine stages them chunk by chunk
+    d_tokens = d_cu = d_out = None
+    if not host_side:
+        d_tokens = torch.from_numpy(flat).to(device)
+        d_cu = torch.from_numpy(cu).to(device)
+        d_out = torch.empty((B, H), dtype=torch.float32, device=device)
+        model.reserve(T, B)
     stream = torch.cuda.current_stream(device)
     counts = [B] * world
     d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
-    model.reserve(T, B)
 
     h_out = np.empty((B, H), dtype=np.float32) if cfg.get("host_step") else None
+    if cfg.get("gather_step"):
+        model.set_option("test_rccl_single", "1")             # one device: the exchange step still runs (1-rank communicator)
+    gathered = {}
 
     def step():
         if cfg.get("host_step"):
             model.eval_packed(flat, cu, out=h_out)            # (the caller's rows, as bert_eval_batch's `float **batch_embeddings`)
+            return
+        if cfg.get("gather_step"):
+            gathered["ptr"] = model.eval_packed_gather(flat, cu)[0]
             return
         model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_out.data_ptr(), stream.cuda_stream)
         if world > 1:
@@ -171,7 +194,16 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     regions = timed_regions(step, steps, warmup if warmup is not None else args.warmup, repeat or args.repeat,
                             lambda: torch.cuda.synchronize(device), dist.barrier if world > 1 else None, reduce_max)
     dt = float(np.median(regions))
-    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=torch.from_numpy(h_out) if h_out is not None else d_out, steps=steps, regions=regions,
+    out = torch.from_numpy(h_out) if h_out is not None else d_out
+    if cfg.get("gather_step"):
+        # the gathered matrix lives in the context's device buffer: fetch a copy through torch (hipMemcpy D2H)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        host = np.empty((B, H), dtype=np.float32)
+        torch.cuda.synchronize(device)
+        assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(gathered["ptr"]), ctypes.c_size_t(host.nbytes), 2) == 0
+        out = torch.from_numpy(host)
+    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=out, steps=steps, regions=regions,
                value=world * B * steps / dt, ms_per_step=1e3 * dt / steps, step=step, tokens=T, max_len=max_len)
     return res
 
@@ -189,7 +221,7 @@ def committed_traffic(cfg_key, kernel):
         return None
 
 
-def kernel_roofline(res, torch, device, steps=5, sync=None):
+def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
     """The dominant kernel's roofline entry.  Two separate passes over the same step, both with HIP events on the launch stream:
     (1) an event pair around EVERY launch: which kernel dominates, launches per step, the per-kernel breakdown (an event pair
         costs tens of microseconds around a sub-millisecond kernel, so these times are upper bounds: `kernel_ms_per_step`);
@@ -212,9 +244,12 @@ def kernel_roofline(res, torch, device, steps=5, sync=None):
     flops = st["flops_per_launch"]
     total_ms = sum(v["total_ms"] for v in rep.values())
     K = int(min(50, max(5, 30e-3 / max(pair_avg_s, 1e-6))))
+    # (the replays run in-place kernels on their own output: the step's result buffer is put back afterwards)
+    out = res.get("out")
+    saved = None if out is None else out.clone()
     model.set_option("profile_replay", f"{name}:{K}")
     samples = []
-    for _ in range(3):
+    for _ in range(groups):
         res["step"]()
         sync()
         r2 = model.profile_report().get(name)
@@ -222,8 +257,8 @@ def kernel_roofline(res, torch, device, steps=5, sync=None):
             samples.append(r2["total_ms"] / r2["launches"] * 1e-3)
     model.set_option("profile_replay", "")
     model.profile(False)
-    res["step"]()                     # (the replays ran in-place kernels on their own output: leave a clean pass behind)
-    sync()
+    if saved is not None:
+        out.copy_(saved)
     avg_s = float(np.median(samples)) if samples else pair_avg_s
     if launches_per_step * avg_s * 1e3 > res["ms_per_step"] * 1.005:
         raise SystemExit(f"bench.py: roofline inconsistent for {name}: {launches_per_step:g} launches x {avg_s * 1e6:.1f} us = "
@@ -298,8 +333,9 @@ def latency_b1(tmpdir, calls=200):
     return out
 
 
-def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None):
-    """Oracle (ggml-faithful mode) on the host cores over a bounded sample of the same sentences."""
+def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None, sample=None):
+    """Oracle (ggml-faithful mode) on the host cores over a bounded sample of the same sentences: by default the step's
+    sentences in order until the time budget is spent; `sample`: exactly these sentence indices."""
     from oracle import oracle as orc
 
     o = orc.Oracle(res["path"])
@@ -312,17 +348,22 @@ def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None):
     sent = lambda i: flat[cu[i]:cu[i + 1]]
     o.eval(sent(0), orc.MODE_GGML, cores)            # warm-up (tables, page-in)
     n, t0, coss = 0, time.perf_counter(), []
-    while n < max_sent and (time.perf_counter() - t0 < budget_s or n < 2):
-        i = n % B                             # bounded sample: cycle through the step's sentences
+    while (n < len(sample)) if sample is not None else (n < max_sent and (time.perf_counter() - t0 < budget_s or n < 2)):
+        i = int(sample[n]) if sample is not None else n % B      # bounded sample: cycle through the step's sentences
         ref = o.eval(sent(i), orc.MODE_GGML, cores)
-        if n < B:
+        if sample is not None or n < B:
             coss.append(float(gpu[i] @ ref / (np.linalg.norm(gpu[i]) * np.linalg.norm(ref))))
         n += 1
     dt = time.perf_counter() - t0
+    what = (f"a fixed random sample of {n} of the step's {B} sentences (numpy default_rng(256))" if sample is not None
+            else f"{n} single-sentence evaluations drawn from the step's sentences")
     base = {"value": n / dt, "unit": "sentences/s", "cores": cores, "kind": "port",
-            "sample": f"{n} single-sentence evaluations drawn from the step's sentences (mean length {res['tokens'] / B:.0f}), oracle ggml-faithful mode, "
+            "sample": f"{what} (mean length {res['tokens'] / B:.0f}), oracle ggml-faithful mode, "
                       f"OpenMP {cores} threads (usable cores {orc.usable_cores()}, logical {os.cpu_count()}), {dt:.1f} s"}
     return base, float(np.mean(coss)), float(np.min(coss)), n
+
+
+SHARE_ROWS = {}       # config4_share: the sampled rows of the host-to-host call, compared with the gather entry point's
 
 
 def report(res, world, torch, device, args, prof_steps, cpu_budget):
@@ -334,6 +375,26 @@ def report(res, world, torch, device, args, prof_steps, cpu_budget):
     e = {"workload": cfg["name"], "value": res["value"], "unit": "sentences/s", "ms_per_step": res["ms_per_step"],
          "regions": {"n": len(r), "steps_each": res["steps"], "median": float(np.median(r)), "min": float(r[0]), "max": float(r[-1])},
          "path_gflop_per_sentence": fps / 1e9, "path_mfma_frac": res["value"] * fps / (world * MFMA_PEAK_F16)}
+    if cfg.get("share"):
+        # one GPU's share of the 1M-sentence config: the step IS the host-to-host (or gather) call
+        sample = np.sort(np.random.default_rng(256).choice(B, size=256, replace=False))
+        rows = res["out"].numpy()[sample].copy()
+        e["entry"] = ("bert_hip_eval_packed_gather (host ids -> [B, H] matrix resident in HBM + the RCCL exchange step on a 1-rank communicator)"
+                      if cfg.get("gather_step") else "bert_hip_eval_packed (host ids -> host embeddings, blocking; 61 chunks of 2048 sentences + one of 72)")
+        e["chunks"] = int(-(-res["tokens"] // 262144))
+        e["bytes_in"], e["bytes_out"] = int(res["flat"].nbytes), int(B * hp.n_embd * 4)
+        if cfg.get("gather_step"):
+            if "rows" in SHARE_ROWS:
+                e["sample_rows_equal_host_call"] = bool(np.array_equal(rows, SHARE_ROWS["rows"]))
+            return e
+        SHARE_ROWS["rows"] = rows
+        roof, bd = kernel_roofline(res, torch, device, steps=1, groups=1)
+        e["roofline"] = roof
+        e["kernel_ms_per_step"] = bd
+        if not args.no_cpu_baseline:
+            base, mc, mn, _ = cpu_baseline_and_cosine(res, gpu=res["out"].numpy(), sample=sample)
+            e.update(cpu_baseline=base, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn, speedup_vs_cpu=res["value"] / base["value"])
+        return e
     roof, bd = kernel_roofline(res, torch, device, steps=prof_steps)
     e["roofline"] = roof
     e["kernel_ms_per_step"] = bd
@@ -395,7 +456,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--also", type=int, nargs="*", default=None,
-                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 4, 5, 55)")
+                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 33, 4, 42, 44, 45, 5, 55)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inproc", action="store_true", help="one process, --gpus N devices inside libbert.so")
     args = ap.parse_args()
@@ -451,12 +512,13 @@ def main():
         else:
             kernel_roofline(res, torch, device)
         res["model"].close()
-        also = args.also if args.also is not None else ([2, 22, 3, 4, 5, 55] if world == 1 and args.config == 1 else [])
+        also = args.also if args.also is not None else ([2, 22, 3, 33, 4, 42, 44, 45, 5, 55] if world == 1 and args.config == 1 else [])
         extras = {}
         for cid in also:
             big = CONFIGS[cid]["dims"] in ("bert-base", "mpnet-dims")
-            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir, steps=3 if big else max(10, args.steps // 4),
-                            warmup=1 if big else 5, repeat=3)
+            share = bool(CONFIGS[cid].get("share"))                   # (a step is one 125,000-sentence call: about three seconds)
+            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir, steps=1 if share else 3 if big else max(10, args.steps // 4),
+                            warmup=1 if big else 5, repeat=2 if share else 3)
             if rank == 0:
                 extras[r2["cfg"].get("key", f"config{cid}")] = report(r2, world, torch, device, args, prof_steps=2 if big else 3,
                                                                        cpu_budget=8.0 if big else 4.0)
@@ -468,6 +530,20 @@ def main():
                 extras["latency_b1"] = latency_b1(tmpdir)
             if extras:
                 line["also"] = extras
+            # the line is long: a compact table of every entry as the LAST object, where a truncated log still shows it
+            def brief(e):
+                r = e.get("roofline") or {}
+                return {k: v for k, v in {"sentences_per_s": round(e["value"], 1) if "value" in e else None, "ms_per_step": round(e["ms_per_step"], 4) if "ms_per_step" in e else None,
+                                          "path_mfma_frac": round(e["path_mfma_frac"], 4) if "path_mfma_frac" in e else None,
+                                          "kernel": r.get("kernel"), "kernel_frac": round(r["frac"], 4) if r.get("frac") is not None else None,
+                                          "kernel_avg_us": round(r["avg_launch_us"], 1) if r.get("avg_launch_us") is not None else None,
+                                          "host_to_host": round(e["host_api"]["value"], 1) if "host_api" in e else None,
+                                          "mean_cosine": e.get("mean_cosine_vs_cpu"), "min_cosine": e.get("min_cosine_vs_cpu"),
+                                          "cpu_sentences_per_s": round(e["cpu_baseline"]["value"], 2) if "cpu_baseline" in e else None,
+                                          "sample_rows_equal_host_call": e.get("sample_rows_equal_host_call")}.items() if v is not None}
+            line["summary"] = {"config1": brief(dict(e, value=res["value"], ms_per_step=res["ms_per_step"]))}
+            for k, v in extras.items():
+                line["summary"][k] = brief(v) if k != "latency_b1" else {kk: round(vv["median_us"], 1) for kk, vv in v.items() if isinstance(vv, dict)}
             print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

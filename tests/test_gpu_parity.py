@@ -92,6 +92,34 @@ def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
         assert not bad.any(), (impl, epi, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
 
 
+@pytest.mark.parametrize("wtype", [2, 3], ids=["q4_0", "q4_1"])
+@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (512, 2304, 768), (257, 768, 3072), (20480, 3072, 768), (33000, 768, 3072), (9000, 256, 128)])
+def test_gemm256_q4_tile_load_gives_the_f16_form_s_bits(M, N, K, wtype):
+    """gemm256 with 4-bit-resident weights (SURVEY §8 row g1 at H = 768: q4_0 / q4_1 blocks dequantised in the GEMM's tile
+    load): a thread fetches its 32-weight block two reduction tiles ahead and expands it into the weight tile's LDS image —
+    the image the f16 form loads by LDS-DMA from the matrix expanded at load.  Same image, same MFMA sequence: EQUAL BITS with
+    the f16 form on the expanded matrix, all three epilogues; sizes with one output tile per workgroup, with several
+    (persistent walk, block requests crossing output tiles), and with the minimum of two reduction tiles."""
+    rng = np.random.default_rng(M + N + K + wtype)
+    A = rng.normal(0, 1, (M, K)).astype(np.float16)
+    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float32)
+    W[:, : K // 2] *= 1.5
+    W[: N // 3] += 0.02
+    bias = rng.normal(0, 0.5, N).astype(np.float32)
+    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
+    q = gf.quantize_q4_0(W) if wtype == 2 else gf.quantize_q4_1(W)
+    img = _q4_image_f16(q, wtype, (N, K))
+    for epi in (0, 1, 2):
+        r = resid if epi == 2 else None
+        got = pybert.test_gemm(A, q.reshape(-1), wtype, N, bias, r, epi, 3)
+        want = pybert.test_gemm(A, img.view(np.uint8).reshape(-1), 1, N, bias, r, epi, 3)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (epi, int((got != want).sum()), np.argwhere(got != want)[:5].tolist())
+    # and the f16 form itself is right (float32 BLAS: the big cases are too large for a float64 product in a test)
+    base = A.astype(np.float32) @ img.astype(np.float32).T + bias
+    err = np.abs(want.astype(np.float32) - (base + resid.astype(np.float32)))
+    assert not (err > 2e-3 * np.abs(base) + 6e-3).any(), float(err.max())
+
+
 @pytest.mark.parametrize("M,H,I", [(200, 128, 256), (256, 256, 512), (130, 384, 1536), (384, 384, 256), (128, 128, 128), (1000, 256, 1024)])
 def test_layer_tail_kernel(M, H, I, impl=1):
     """Out-projection + LN + FFN + LN in one launch (layer_tail.hip) and as five kernels (three GEMMs, two LayerNorms: the
@@ -701,11 +729,18 @@ def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes through size-independent properties
 # ------------------------------------------------------------------------------------------------
-def test_full_size_batch_properties_bert_base(make_model):
+_FULL_SIZE_OUT = {}       # (config, q4 mode) -> embeddings: the fused run is compared with the default's bits
+
+
+@pytest.mark.parametrize("q4", ["expand", "fused"])
+def test_full_size_batch_properties_bert_base(make_model, q4, monkeypatch):
     """configs[3] at full size: bert-base dims q4_1, 512 sentences of 512 tokens.  Unit norm, duplicates give identical
     bits wherever they sit, the kernels the H = 768 path is meant to use are the ones that ran, and eight sentences spread
-    over the batch agree with the oracle (ggml-faithful mode)."""
+    over the batch agree with the oracle (ggml-faithful mode).  Both ways: the q4 matrices expanded to f16 at load (the
+    default) and as BASELINE.json writes the config — 4-bit in HBM, dequantised in gemm256's tile load (kernel family
+    asserted: every weight mat-mul of the pass ran on gemm256 with q4 planes) — with EQUAL BITS between the two."""
     path, hp = make_model("bert-base", "q4_1", 0)
+    monkeypatch.setenv("BERT_HIP_Q4", q4)
     m = pybert.BertModel(path)
     B, N = 512, 512
     ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 3)
@@ -714,12 +749,17 @@ def test_full_size_batch_properties_bert_base(make_model):
     cu = (np.arange(B + 1) * N).astype(np.int32)
     m.profile(True)
     out = m.eval_packed(ids.reshape(-1), cu)
-    rep = m.profile_report()
+    rep = m.profile_report(families=True)
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention", "layernorm"} <= set(rep), sorted(rep)
+    fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
+    assert fam == {"family:gemm256_q4" if q4 == "fused" else "family:gemm256_f16": 4 * hp.n_layer}, fam
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
+    _FULL_SIZE_OUT[("bert-base", q4)] = out
+    if q4 == "fused" and ("bert-base", "expand") in _FULL_SIZE_OUT:
+        assert np.array_equal(out, _FULL_SIZE_OUT[("bert-base", "expand")])
     o = orc.Oracle(path)
     sample = [0, 3, 77, B // 3, B // 2 + 5, 400, B - 2, B - 1]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
@@ -764,11 +804,13 @@ def test_full_size_batch_properties(make_model, ftype, B, q4, monkeypatch):
     assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample) >= TIGHT_COS_PLAIN
 
 
-def test_full_size_batch_properties_mpnet_dims(make_model):
-    """configs[4]'s model (BERT architecture at mpnet-base dimensions, q4_0) at one GPU's share of a step: 1024 sentences of
-    128 tokens.  Unit norm, duplicates give identical bits, the H = 768 kernel family ran, and six sentences spread over
-    the batch agree with both oracle modes."""
+@pytest.mark.parametrize("q4", ["expand", "fused"])
+def test_full_size_batch_properties_mpnet_dims(make_model, q4, monkeypatch):
+    """configs[4]'s model (BERT architecture at mpnet-base dimensions, q4_0), 1024 sentences of 128 tokens.  Unit norm,
+    duplicates give identical bits, the H = 768 kernel family ran (with BERT_HIP_Q4=fused: on 4-bit planes, equal bits with
+    the default), and six sentences spread over the batch agree with both oracle modes."""
     path, hp = make_model("mpnet-dims", "q4_0", 0)
+    monkeypatch.setenv("BERT_HIP_Q4", q4)
     m = pybert.BertModel(path)
     B, N = 1024, 128
     ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 4)
@@ -777,14 +819,55 @@ def test_full_size_batch_properties_mpnet_dims(make_model):
     cu = (np.arange(B + 1) * N).astype(np.int32)
     m.profile(True)
     out = m.eval_packed(ids.reshape(-1), cu)
-    rep = m.profile_report()
+    rep = m.profile_report(families=True)
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention"} <= set(rep), sorted(rep)
+    fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
+    assert fam == {"family:gemm256_q4" if q4 == "fused" else "family:gemm256_f16": 4 * hp.n_layer}, fam
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
+    _FULL_SIZE_OUT[("mpnet-dims", q4)] = out
+    if q4 == "fused" and ("mpnet-dims", "expand") in _FULL_SIZE_OUT:
+        assert np.array_equal(out, _FULL_SIZE_OUT[("mpnet-dims", "expand")])
     o = orc.Oracle(path)
     sample = [0, 3, B // 3, B // 2 + 5, B - 2, B - 1]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
     assert min(coss) >= TIGHT_COS_GGML["q4_0"], coss
     assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample[:3]) >= TIGHT_COS_PLAIN
+
+
+def test_config5_share_one_call_of_125000_sentences(make_model):
+    """BASELINE configs[4] as SURVEY §8(d) writes it ("Config 5"): 1,000,000 sentences of 128 tokens over 8 GPUs = 125,000 per
+    GPU, through ONE host-to-host call (bert_hip_eval_packed: what bert_eval_batch runs) — 61 chunks of 2048 sentences through
+    the two-slot staging pipeline of engine.hip, 64 MB of ids in, 384 MB of embeddings out.  The pipeline gives the bits of
+    single-chunk calls (chunks from the start, the middle, the end and the ragged last one), duplicates placed in far-apart
+    chunks come back identical, every row has unit norm, and a fixed sample agrees with the oracle.  The same call through
+    bert_hip_eval_packed_gather (the path's exchange step, a 1-rank RCCL communicator here) returns the same matrix."""
+    from test_multi_device import _Hip
+    path, hp = make_model("mpnet-dims", "q4_0", 0)
+    m = pybert.BertModel(path)
+    B, N, H = 125000, 128, hp.n_embd
+    ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 4)
+    for dup in (70000, B - 1):
+        ids[dup] = ids[3]
+    cu = (np.arange(B + 1, dtype=np.int64) * N).astype(np.int32)
+    out = m.eval_packed(ids.reshape(-1), cu)
+    assert np.isfinite(out).all()
+    assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
+    assert np.array_equal(out[3], out[70000]) and np.array_equal(out[3], out[B - 1])
+    per_chunk = 262144 // N
+    n_chunks = (B + per_chunk - 1) // per_chunk
+    assert n_chunks == 62 and B - 61 * per_chunk == 72          # 61 full chunks + a last one of 72 sentences
+    for c in (0, 1, 30, 60, 61):
+        b0, b1 = c * per_chunk, min(B, (c + 1) * per_chunk)
+        single = m.eval_packed(ids[b0:b1].reshape(-1), cu[: b1 - b0 + 1])
+        assert np.array_equal(single, out[b0:b1]), c
+    o = orc.Oracle(path)
+    sample = np.random.default_rng(5).choice(B, size=6, replace=False)
+    coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
+    assert min(coss) >= TIGHT_COS_GGML["q4_0"], coss
+    hip = _Hip()
+    m.set_option("test_rccl_single", "1")
+    ptrs = m.eval_packed_gather(ids.reshape(-1), cu)
+    assert np.array_equal(hip.download(ptrs[0], (B, H)), out)
