@@ -250,8 +250,8 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
             if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-    if (wide) hipLaunchKernelGGL((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
-    else hipLaunchKernelGGL((attention_mfma_kernel<D, 256, 128>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
+    if (wide) BERT_LAUNCH((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
+    else BERT_LAUNCH((attention_mfma_kernel<D, 256, 128>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }
 
 bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,
@@ -306,7 +306,7 @@ void launch_attention_naive(const half_t *qkv, const int32_t *cu_seqlens, int n_
     const int qblocks = (max_len + 3) / 4;
     dim3 grid(qblocks, n_sentences, n_head);
     const size_t lds = (size_t)4 * qblocks * 4 * sizeof(float);
-    hipLaunchKernelGGL(attention_naive_kernel, grid, dim3(256), lds, stream, qkv, cu_seqlens, n_head, d_head, out);
+    BERT_LAUNCH(attention_naive_kernel, grid, dim3(256), lds, stream, qkv, cu_seqlens, n_head, d_head, out);
 }
 
 }  // namespace bert_hip

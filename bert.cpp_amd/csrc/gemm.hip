@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs p) {
 template <int WT>
 static void launch_wt(const GemmArgs &a, int grid, int epilogue, hipStream_t s) {
     switch (epilogue) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_mfma_kernel<WT, EPI_BIAS>), dim3(grid), dim3(256), 0, s, a); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_mfma_kernel<WT, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((gemm_mfma_kernel<WT, EPI_BIAS_RESID>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_BIAS: BERT_LAUNCH((gemm_mfma_kernel<WT, EPI_BIAS>), dim3(grid), dim3(256), 0, s, a); break;
+        case EPI_BIAS_GELU: BERT_LAUNCH((gemm_mfma_kernel<WT, EPI_BIAS_GELU>), dim3(grid), dim3(256), 0, s, a); break;
+        default: BERT_LAUNCH((gemm_mfma_kernel<WT, EPI_BIAS_RESID>), dim3(grid), dim3(256), 0, s, a); break;
     }
 }
 
@@ -289,9 +289,9 @@ void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, 
                        int M, int epilogue, hipStream_t stream) {
     dim3 grid((W.N + 63) / 64, (M + 3) / 4), block(256);
     switch (epilogue) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_naive_kernel<EPI_BIAS>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_naive_kernel<EPI_BIAS_GELU>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
-        default: hipLaunchKernelGGL((gemm_naive_kernel<EPI_BIAS_RESID>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
+        case EPI_BIAS: BERT_LAUNCH((gemm_naive_kernel<EPI_BIAS>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
+        case EPI_BIAS_GELU: BERT_LAUNCH((gemm_naive_kernel<EPI_BIAS_GELU>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
+        default: BERT_LAUNCH((gemm_naive_kernel<EPI_BIAS_RESID>), grid, block, 0, stream, A, W.naive16, bias, resid, C, M, W.N, W.K); break;
     }
 }
 

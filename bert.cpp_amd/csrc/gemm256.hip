@@ -535,7 +535,7 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     static DeviceFlags configured[9];
     auto go = [&](auto kernel, int e) {
         configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
+        BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
     auto by_type = [&](auto epi_tag) {
         constexpr int E = decltype(epi_tag)::value;

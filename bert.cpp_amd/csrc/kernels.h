@@ -4,6 +4,7 @@
 // Activations are f16 row-major [T_pad][features]; T_pad is T rounded up to GEMM_BM tokens.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <atomic>
 #include <cstdint>
@@ -177,6 +178,20 @@ template <class F>
 inline void configure_once(DeviceFlags &seen, F &&opt_in) {
     if (first_launch_on_device(seen)) { opt_in(); mark_configured(seen); }
 }
+
+// Every kernel of the path is launched through BERT_LAUNCH.  While the engine profiles (Engine::timed) the launching thread
+// points tl_launch_timing at an event pair and the launch goes through hipExtLaunchKernelGGL, which stamps the events with the
+// DISPATCH's own begin / end timestamps — the interval rocprofv3's kernel trace reports — instead of bracketing the launch with
+// hipEventRecord barrier packets (those add tens of microseconds around a sub-millisecond kernel).
+struct LaunchTiming { hipEvent_t start, stop; };
+inline thread_local const LaunchTiming *tl_launch_timing = nullptr;
+#define BERT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                     \
+    do {                                                                                                                      \
+        if (::bert_hip::tl_launch_timing)                                                                                     \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ::bert_hip::tl_launch_timing->start,                      \
+                                  ::bert_hip::tl_launch_timing->stop, 0, __VA_ARGS__);                                        \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                               \
+    } while (0)
 
 // f16 [rows][cols] -> f32 (hidden-state tap)
 void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream);

@@ -931,7 +931,7 @@ void launch_layer_tail(const GemmWeight &Wo, const GemmWeight &W1, const GemmWei
     static DeviceFlags configured[6];
     auto go = [&](auto kernel, int which) {
         configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        hipLaunchKernelGGL(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
+        BERT_LAUNCH(kernel, dim3(M_pad / 128), dim3(512), lds, stream, a);
 #ifdef BERT_HIP_TIMELINE
         static int shots = 0;
         if (M_pad >= 128 * 256 && shots++ == 20) {

@@ -215,9 +215,9 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
         const bool search = n_sentences > 65535 || 2ll * ((max_len + 3) / 4) * n_sentences > 3ll * ((T + 3) / 4);
         const dim3 g2 = search ? dim3((T + 3) / 4) : dim3((max_len + 3) / 4, n_sentences), b2(256);
 #define EMBR(TT, NC) do { \
-            if (search) hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC, true>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
+            if (search) BERT_LAUNCH((embed_ln_rows_kernel<TT, NC, true>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
                                            cu_seqlens, n_sentences, T, H, n_vocab, out); \
-            else hipLaunchKernelGGL((embed_ln_rows_kernel<TT, NC, false>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
+            else BERT_LAUNCH((embed_ln_rows_kernel<TT, NC, false>), g2, b2, 0, stream, word, type, pos, gamma, beta, tokens, \
                                     cu_seqlens, n_sentences, T, H, n_vocab, out); } while (0)
         if (table_type == 0) { if (H <= 512) EMBR(0, 1); else EMBR(0, 2); }
         else if (table_type == 1) { if (H <= 512) EMBR(1, 1); else EMBR(1, 2); }
@@ -228,7 +228,7 @@ void launch_embed_ln(const void *word, const void *type, const void *pos, int ta
     }
     const dim3 grid((T + 3) / 4), block(256);
     const int nj = (H + 127) / 128;
-#define EMB(NJ) hipLaunchKernelGGL(embed_ln_kernel<NJ>, grid, block, 0, stream, word, type, pos, table_type, gamma, \
+#define EMB(NJ) BERT_LAUNCH(embed_ln_kernel<NJ>, grid, block, 0, stream, word, type, pos, table_type, gamma, \
                                    beta, tokens, cu_seqlens, n_sentences, T, H, n_vocab, out)
     if (nj <= 1) EMB(1); else if (nj <= 3) EMB(3); else if (nj <= 6) EMB(6); else if (nj <= 8) EMB(8); else EMB(32);
 #undef EMB
@@ -324,18 +324,18 @@ void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, i
     if (T <= 0) return;
     if (H % 8 == 0 && H <= 2048) {
         const dim3 grid((T + 3) / 4), block(256);
-        if (H <= 512) hipLaunchKernelGGL(layernorm_rows_kernel<1>, grid, block, 0, stream, x, gamma, beta, T, H);
-        else if (H <= 1024) hipLaunchKernelGGL(layernorm_rows_kernel<2>, grid, block, 0, stream, x, gamma, beta, T, H);
-        else hipLaunchKernelGGL(layernorm_rows_kernel<4>, grid, block, 0, stream, x, gamma, beta, T, H);
+        if (H <= 512) BERT_LAUNCH(layernorm_rows_kernel<1>, grid, block, 0, stream, x, gamma, beta, T, H);
+        else if (H <= 1024) BERT_LAUNCH(layernorm_rows_kernel<2>, grid, block, 0, stream, x, gamma, beta, T, H);
+        else BERT_LAUNCH(layernorm_rows_kernel<4>, grid, block, 0, stream, x, gamma, beta, T, H);
         return;
     }
     const dim3 grid((T + 3) / 4), block(256);
     const int nj = (H + 127) / 128;      // H must be even (checked at load)
-    if (nj <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, T, H);
-    else if (nj <= 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, T, H);
-    else if (nj <= 6) hipLaunchKernelGGL(layernorm_kernel<6>, grid, block, 0, stream, x, gamma, beta, T, H);
-    else if (nj <= 8) hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, stream, x, gamma, beta, T, H);
-    else hipLaunchKernelGGL(layernorm_kernel<32>, grid, block, 0, stream, x, gamma, beta, T, H);   // H <= 4096
+    if (nj <= 1) BERT_LAUNCH(layernorm_kernel<1>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 3) BERT_LAUNCH(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 6) BERT_LAUNCH(layernorm_kernel<6>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else if (nj <= 8) BERT_LAUNCH(layernorm_kernel<8>, grid, block, 0, stream, x, gamma, beta, T, H);
+    else BERT_LAUNCH(layernorm_kernel<32>, grid, block, 0, stream, x, gamma, beta, T, H);   // H <= 4096
 }
 
 // reference bert.cpp:904-913: mean over all N tokens (mat-vec with a 1/N vector), then y / ||y||_2.
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, co
 void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status,
                            float *out, hipStream_t stream) {
     if (n_sentences <= 0) return;
-    hipLaunchKernelGGL(pool_normalize_kernel, dim3(n_sentences), dim3(256), (4 * H + 4) * sizeof(float), stream, x,
+    BERT_LAUNCH(pool_normalize_kernel, dim3(n_sentences), dim3(256), (4 * H + 4) * sizeof(float), stream, x,
                        cu_seqlens, H, max_len, status, out);
 }
 
@@ -362,7 +362,7 @@ __global__ void f16_to_f32_kernel(const half_t *src, float *dst, size_t n) {
 
 void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream) {
     if (!n) return;
-    hipLaunchKernelGGL(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+    BERT_LAUNCH(f16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
 }
 
 }  // namespace bert_hip

@@ -162,7 +162,7 @@ void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x
     static DeviceFlags configured[4];
     auto go = [&](auto kernel, int which) {
         configure_once(configured[which], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, m);
+        BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, m);
 #ifdef BERT_HIP_MODEL_TIMELINE
         static int shots = 0;
         if (grid >= 256 && shots++ == 30) {

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t
 }
 
 void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream) {
-    hipLaunchKernelGGL(build_windows_kernel, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
+    BERT_LAUNCH(build_windows_kernel, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
 }
 
 int qkv_attention2_max_windows(int n_sentences, int n_tokens) {
@@ -642,7 +642,7 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
     static DeviceFlags configured[3][8];
     auto go = [&](auto kernel) {
         configure_once(configured[Wqkv.type][KT], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), lds, stream, a);
+        BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
         TL_DUMP_RAW(grid >= 256, 256);
     };
     switch (KT * 4 + Wqkv.type) {

@@ -232,7 +232,7 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
     static DeviceFlags configured[8];
     auto go = [&](auto kernel, int m) {
         if (lds > 64 * 1024) configure_once(configured[m], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+        BERT_LAUNCH(kernel, grid, block, lds, stream, a);
     };
     const bool nt2 = W.K == 256;                             // (only the LayerNorm-fused forms depend on NT: K = H there)
     switch (mode) {
@@ -252,8 +252,8 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
 void launch_skinny_layernorm(const float *v, const float *gamma, const float *beta, half_t *out, int n_token_blocks, int H,
                              hipStream_t stream) {
     const dim3 grid(n_token_blocks), block(64);
-    if (H == 256) hipLaunchKernelGGL(skinny_layernorm_kernel<2>, grid, block, 0, stream, v, gamma, beta, out);
-    else hipLaunchKernelGGL(skinny_layernorm_kernel<3>, grid, block, 0, stream, v, gamma, beta, out);
+    if (H == 256) BERT_LAUNCH(skinny_layernorm_kernel<2>, grid, block, 0, stream, v, gamma, beta, out);
+    else BERT_LAUNCH(skinny_layernorm_kernel<3>, grid, block, 0, stream, v, gamma, beta, out);
 }
 
 }  // namespace bert_hip
