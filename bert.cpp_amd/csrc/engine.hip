@@ -352,7 +352,7 @@ void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
         pending_.push_back(p);
         return;
     }
-    // an event pair stamped with the dispatch's own begin / end (kernels.h BERT_LAUNCH): the kernel's time as a kernel trace sees it
+    // an event pair attached to the dispatch itself (kernels.h BERT_LAUNCH): an upper bound of the kernel's time in the pass
     Pending p{name, get(), get(), flops, 1};
     const LaunchTiming lt{p.a, p.b};
     tl_launch_timing = &lt;

@@ -180,9 +180,12 @@ inline void configure_once(DeviceFlags &seen, F &&opt_in) {
 }
 
 // Every kernel of the path is launched through BERT_LAUNCH.  While the engine profiles (Engine::timed) the launching thread
-// points tl_launch_timing at an event pair and the launch goes through hipExtLaunchKernelGGL, which stamps the events with the
-// DISPATCH's own begin / end timestamps — the interval rocprofv3's kernel trace reports — instead of bracketing the launch with
-// hipEventRecord barrier packets (those add tens of microseconds around a sub-millisecond kernel).
+// points tl_launch_timing at an event pair and the launch goes through hipExtLaunchKernelGGL, which attaches the events to the
+// dispatch itself (no hipEventRecord barrier packets of their own in the stream).  Measured (round 4): a launch timed this
+// way still runs with system-scope fences — L2 written back and invalidated around it — so a sub-millisecond kernel that lives
+// on L2-resident weights reads 5-8 % long (model_kernel 841 us against 777 us in rocprofv3's trace); for kernels of a
+// millisecond and more the two agree within 1 %.  These times feed the per-kernel BREAKDOWN; the roofline's kernel time comes
+// from the replay form (engine.hip timed(): K launches between one event pair).
 struct LaunchTiming { hipEvent_t start, stop; };
 inline thread_local const LaunchTiming *tl_launch_timing = nullptr;
 #define BERT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                     \

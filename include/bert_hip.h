@@ -88,8 +88,8 @@ BERT_API int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id 
                                       float *hidden, float *embedding);
 
 /* Per-kernel timing with HIP events on the launch stream.  While enabled every kernel launch of
- * the forward pass is bracketed by events (this serialises nothing but adds event overhead, so
- * never enable it inside a throughput measurement).  bert_hip_profile_report writes one line per
+ * the forward pass carries an event pair (hipExtLaunchKernelGGL start / stop events: a timed launch runs behind system-scope
+ * fences and reads up to 8 % long for sub-millisecond kernels, so never enable it inside a throughput measurement).  bert_hip_profile_report writes one line per
  * kernel: "<name> <launches> <total_ms> <flops_per_launch_avg>\n" and returns the number of bytes
  * it needed (excluding NUL); it synchronises the device first and resets the counters.  Behind the kernels it lists which
  * mat-mul kernel family served the weight GEMMs of the pass: "family:gemm256_f16" / "family:gemm256_q4" (256 x 256 tiles, f16

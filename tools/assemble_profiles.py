@@ -6,7 +6,7 @@ import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
 P = os.path.join(root, "profiles")
@@ -47,15 +47,17 @@ for k in ("model_kernel", "layer_tail", "qkv_attention2"):
 bench = json.loads(read(f"bench_{tag}.log"))
 hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
        f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers: ONE launch for all layers (model_kernel: a workgroup per window, qkv_attention2 + layer_tail as phases)\n"
-       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), HIP events {bench['roofline']['kernel']} {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
+       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), its own time of {bench['roofline']['kernel']} ({bench['roofline']['timing']}): {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
        "# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): " +
        ", ".join(f"{k} {v[0] / 1e6:.2f} M / (1024 x {v[1] / 1e3:.1f} k) = {v[2]:.2f}" for k, v in busy.items()) + " (two launches per layer, earlier this round: layer_tail 0.41, qkv_attention2 0.34)\n")
 c3 = bench["also"]["config3"]
 with open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w") as f:
     f.write(hdr + read(f"stats_{tag}.txt") +
             f"\n# --config 3 (bert-base dims q4_1 expanded to f16 at load, 512 x 512 tokens per step, 12 layers): rocprofv3 --kernel-trace --stats -- python bench.py --config 3 --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --also\n"
-            f"# gemm256_kernel<0> = QKV (bias), <1> = FFN up (bias + GELU), <2> = attention output and FFN down (bias + residual); same box un-profiled: {c3['value']:.0f} sentences/s = {c3['path_mfma_frac']:.3f} of the MFMA peak\n" +
-            read(f"stats_config3_{tag}.txt"))
+            f"# gemm256_kernel<EPI, WT>: EPI 0 = QKV (bias), 1 = FFN up (bias + GELU), 2 = attention output and FFN down (bias + residual); WT 0 = f16 image; same box un-profiled: {c3['value']:.0f} sentences/s = {c3['path_mfma_frac']:.3f} of the MFMA peak\n" +
+            read(f"stats_config3_{tag}.txt") +
+            (f"\n# --config 33: the same model and batch with BERT_HIP_Q4=fused — the matrices stay 4-bit in HBM, gemm256_kernel<EPI, 2> (q4_1 planes) dequantises the blocks in its tile load; same box un-profiled: "
+             f"{bench['also']['config3_fused']['value']:.0f} sentences/s\n" + read(f"stats_config33_{tag}.txt") if os.path.exists(os.path.join(g, f"stats_config33_{tag}.txt")) and "config3_fused" in bench["also"] else ""))
 with open(os.path.join(P, f"{tag}_pmc.txt"), "w") as f:
     f.write(f"# rocprofv3 --pmc <set> --kernel-trace -- python bench.py --steps 2 --warmup 1 --repeat 1 --no-cpu-baseline --also   (separate runs per counter set; mean per dispatch; commit {commit})\n"
             "# SQ_* in quad-cycles except SQ_VALU_MFMA_BUSY_CYCLES (cycles); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md, HBM section)\n" +

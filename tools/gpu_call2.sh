@@ -16,7 +16,7 @@ python tools/rocpd_summary.py stats $(find $OUT/prof_c2 -name '*_results.db' | h
 python - <<PY
 import json
 d=json.loads([l for l in open("$OUT/bench_c2_prof.log") if l.startswith("{")][-1])
-print("under rocprof:", {k:d[k] for k in ("value","ms_per_step")}, {k:d["roofline"][k] for k in ("avg_launch_us","frac","replay_avg_us","step_share")})
+print("under rocprof:", {k:d[k] for k in ("value","ms_per_step")}, {k:d["roofline"][k] for k in ("avg_launch_us","frac","avg_launch_us_timed_alone","step_share")})
 PY
 timeout 300 python bench.py --config 3 --also --no-cpu-baseline --steps 3 --warmup 1 --repeat 2 > $OUT/bench_c2_3.log 2>&1; python - <<PY
 import json

@@ -16,7 +16,8 @@ NAMES = {"qkv_attention2_kernel": "qkv_attention2", "layer_tail_kernel": "layer_
          "layernorm_rows_kernel": "layernorm",
          # gemm256_kernel<EPI>: 0 = bias (Q|K|V), 1 = bias + GELU (FFN up), 2 = bias + residual (attention output AND FFN down:
          # one kernel, two shapes; their mean is booked under gemm_ffn_down)
-         "gemm256_kernel<0>": "gemm_qkv", "gemm256_kernel<1>": "gemm_ffn_up", "gemm256_kernel<2>": "gemm_ffn_down"}
+         # (second template argument: the weight form — 0 f16 image, 1 q4_0 planes, 2 q4_1 planes)
+         "gemm256_kernel<0,": "gemm_qkv", "gemm256_kernel<1,": "gemm_ffn_up", "gemm256_kernel<2,": "gemm_ffn_down"}
 
 
 def counter_means(path, counter):
