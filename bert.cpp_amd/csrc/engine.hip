@@ -218,6 +218,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
+    if (const char *c = getenv("BERT_HIP_HOST_EVENT_SCOPE")) e->host_event_device_scope_ = strcmp(c, "device") == 0;
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
     auto T = [&](const std::string &n) { return mf.find(n); };
@@ -260,7 +261,11 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     }
     ok = ok && e->status_.alloc(16, err);
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
-    if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
+    // busy_ orders passes of ONE device against each other (the shared workspace): a device-scope release is all it needs.  With
+    // the default system-scope fence every pass ended with the L2s written back and the next pass's first kernel started behind
+    // an invalidate — the all-layers kernel then re-fetched its 20 MB of weights into every XCD's L2 on every step: 780 us in the
+    // step against 720 us for the same launch repeated back to back (round 4, rocprofv3 + bench.py's replay groups).
+    if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
     if (!ok) { delete e; return nullptr; }
     return e;
 }
@@ -312,6 +317,13 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
+    else if (key == "host_event_scope") {
+        // "device": the host path's chunk-done events skip the system-scope fence too (the embeddings go to pinned, fine-grained
+        // host memory straight from the kernel; the event only has to say that the pass is over); "system" (default)
+        host_event_device_scope_ = value == "device";
+        for (auto &sl : slot_)
+            if (sl.done) { (void)hipEventDestroy(sl.done); sl.done = nullptr; }
+    }
     else if (key == "profile_replay") {
         // "<kernel name>:<K>" (see timed()), "" switches back to an event pair per launch
         const size_t c = value.rfind(':');
@@ -334,7 +346,7 @@ void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
     auto get = [&]() {
         hipEvent_t ev;
         if (!ev_pool_.empty()) { ev = ev_pool_.back(); ev_pool_.pop_back(); }
-        else (void)hipEventCreate(&ev);
+        else (void)hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);     // (timing only: no cache write-back / invalidate around the timed launch)
         return ev;
     };
     if (!replay_name_.empty()) {
@@ -607,7 +619,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         if (sl.h_out_cap != out_cap || !sl.d_out_host)
             HIP_OK(hipHostGetDevicePointer((void **)&sl.d_out_host, sl.h_out, 0), err, -1);
         if (!sl.d_in.ensure(in_bytes, err) || (d_embeddings && !sl.d_out.ensure(max_nb * H * 4, err))) return -1;
-        if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
+        if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (host_event_device_scope_ ? hipEventDisableSystemFence : 0)), err, -1);
     }
     if (!ensure_workspace((int)((max_T + 255) / 256 * 256), (int)max_nb, err)) return -1;
 
