@@ -221,19 +221,27 @@ def committed_traffic(cfg_key, kernel):
         return None
 
 
+# kernels that work IN PLACE (x -> x): a repeat of one of their launches runs on its own output
+IN_PLACE_KERNELS = {"model_kernel", "layer_tail", "layernorm", "skinny_layernorm"}
+
+
 def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
-    """The dominant kernel's roofline entry, measured live on the launch stream.
-    (1) One pass over `steps` steps with an event pair per launch (stamped through hipExtLaunchKernelGGL): which kernel
-        dominates, launches per step, the per-kernel breakdown `kernel_ms_per_step`.  A timed launch is an UPPER bound of the
-        kernel's time in the step: the events give the dispatch system-scope fences — the L2s are written back and invalidated
-        around it — which costs a sub-millisecond kernel that lives on L2-resident weights 5-8 % (model_kernel: 841 us timed,
-        777 us in rocprofv3's trace of the same box, 799 us for the WHOLE un-profiled step).
-    (2) `avg_launch_us`, the number the roofline uses: K back-to-back repeats of one launch of the dominant kernel between ONE
-        event pair (the engine's "profile_replay" option), median of `groups` such groups — the pair's cost is spread over K
-        launches and the launches in between keep the fences the step's own launches have.  Checked against the step it belongs
-        to: launches_per_step x avg_launch_us may not exceed ms_per_step (bench.py fails loudly otherwise).
-    rocprofv3 --kernel-trace --stats of this same command is committed under profiles/ (r4_kernel_stats.txt) together with the
-    line bench.py printed UNDER the profiler: compare like with like — a profiled process runs 2-4 % slower (clocks)."""
+    """The dominant kernel's roofline entry, measured live on the launch stream with HIP events.
+    (1) One pass over `steps` steps with an event pair per launch: which kernel dominates, launches per step, the per-kernel
+        breakdown `kernel_ms_per_step`.  A launch timed alone reads LONG — a sub-millisecond kernel that lives on cache-resident
+        weights by 5-10 % (model_kernel: 825-866 us timed alone, 780 us in rocprofv3's trace of the same steps) — so these are
+        upper bounds and not what the roofline uses.
+    (2) `avg_launch_us`.  Replay groups (the engine's "profile_replay" option): K back-to-back repeats of ONE launch of a kernel
+        between ONE event pair, median of `groups` groups — the pair's cost is spread over K launches.
+        - dominant kernel NOT in place (the GEMMs, attention, qkv_attention2): its own replay groups;
+        - dominant kernel IN PLACE (model_kernel, layer_tail: x -> x): repeats would run on their own output, and activations
+          pushed through the encoder again and again converge — such operands draw less power and the repeats run 7 % fast
+          (measured: 720 us against 780 us in the step).  Its time is the STEP's time (the timed region's ms_per_step: the
+          GPU is never idle in it) minus the replay-group times of the step's OTHER kernels (embedding, pooling, window
+          kernels: all replay-safe), divided by its launches per step.
+        Either way launches_per_step x avg_launch_us cannot exceed ms_per_step; bench.py fails loudly if it does.
+    rocprofv3 --kernel-trace --stats of this same command is committed under profiles/ together with the line bench.py printed
+    UNDER the profiler: compare like with like — a profiled process runs 2-4 % slower (clocks)."""
     model = res["model"]
     sync = sync or (lambda: torch.cuda.synchronize(device))
     model.profile(True)
@@ -246,39 +254,48 @@ def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
         return None, rep
     name, st = max(rep.items(), key=lambda kv: kv[1]["total_ms"])
     pair_avg_s = st["total_ms"] / st["launches"] * 1e-3
-    launches_per_step = st["launches"] / steps
+    per_step = {k: v["launches"] / steps for k, v in rep.items()}
     flops = st["flops_per_launch"]
     total_ms = sum(v["total_ms"] for v in rep.values())
-    # (the repeats run in-place kernels on their own output: the step's result buffer is put back afterwards)
-    K = int(min(50, max(5, 30e-3 / max(pair_avg_s, 1e-6))))
+
+    def replay_avg(kernel, alone_s):
+        K = int(min(50, max(5, 30e-3 / max(alone_s, 1e-6))))
+        model.set_option("profile_replay", f"{kernel}:{K}")
+        samples = []
+        for _ in range(max(1, groups)):
+            res["step"]()
+            sync()
+            r2 = model.profile_report().get(kernel)
+            if r2 and r2["launches"]:
+                samples.append(r2["total_ms"] / r2["launches"] * 1e-3)
+        model.set_option("profile_replay", "")
+        return (float(np.median(samples)) if samples else alone_s), K, len(samples)
+
     out = res.get("out")
     saved = None if out is None else out.clone()
-    model.set_option("profile_replay", f"{name}:{K}")
-    samples = []
-    for _ in range(max(1, groups)):
-        res["step"]()
-        sync()
-        r2 = model.profile_report().get(name)
-        if r2 and r2["launches"]:
-            samples.append(r2["total_ms"] / r2["launches"] * 1e-3)
-    model.set_option("profile_replay", "")
+    if name in IN_PLACE_KERNELS:
+        others = {k: replay_avg(k, rep[k]["total_ms"] / rep[k]["launches"] * 1e-3)[0] for k in rep if k != name}
+        others_ms = sum(per_step[k] * t * 1e3 for k, t in others.items())
+        avg_s = (res["ms_per_step"] - others_ms) * 1e-3 / per_step[name]
+        timing = (f"in-place kernel: step time ({res['ms_per_step']:.4f} ms) minus the replay-group times of the step's other kernels "
+                  f"({', '.join(f'{k} {per_step[k]:g} x {t * 1e6:.1f} us' for k, t in sorted(others.items()))}), over {per_step[name]:g} launches per step")
+    else:
+        avg_s, K, n = replay_avg(name, pair_avg_s)
+        timing = f"{K} back-to-back launches between one HIP event pair on the launch stream, median of {n} such groups"
     model.profile(False)
     if saved is not None:
         out.copy_(saved)
-    avg_s = float(np.median(samples)) if samples else pair_avg_s
-    if launches_per_step * avg_s * 1e3 > res["ms_per_step"] * 1.005:
-        raise SystemExit(f"bench.py: roofline inconsistent for {name}: {launches_per_step:g} launches x {avg_s * 1e6:.1f} us = "
-                         f"{launches_per_step * avg_s * 1e3:.4f} ms exceeds ms_per_step = {res['ms_per_step']:.4f} (groups "
-                         f"{[round(x * 1e6, 1) for x in samples]} us, one timed launch {pair_avg_s * 1e6:.1f} us)")
-    achieved = flops / avg_s if avg_s > 0 else 0.0
+    if per_step[name] * avg_s * 1e3 > res["ms_per_step"] * 1.005 or avg_s <= 0:
+        raise SystemExit(f"bench.py: roofline inconsistent for {name}: {per_step[name]:g} launches x {avg_s * 1e6:.1f} us = "
+                         f"{per_step[name] * avg_s * 1e3:.4f} ms against ms_per_step = {res['ms_per_step']:.4f} (one launch timed alone {pair_avg_s * 1e6:.1f} us)")
+    achieved = flops / avg_s
     key = res["cfg"].get("key", f"config{res['cfg_id']}")
     roof = {"bound": "mfma", "kernel": name, "achieved": achieved / 1e12, "peak": MFMA_PEAK_F16 / 1e12,
             "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_F16, "traffic": committed_traffic(key, name),
             "mfma_rate_under_power_limit": MFMA_RATE_RANDOM_F16 / 1e12, "frac_of_that": achieved / MFMA_RATE_RANDOM_F16,
-            "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops, "launches_per_step": launches_per_step,
-            "timing": f"{K} back-to-back launches between one HIP event pair on the launch stream, median of {len(samples)} such groups",
-            "avg_launch_us_timed_alone": pair_avg_s * 1e6,
-            "step_share": launches_per_step * avg_s * 1e3 / res["ms_per_step"],
+            "avg_launch_us": avg_s * 1e6, "flops_per_launch": flops, "launches_per_step": per_step[name],
+            "timing": timing, "avg_launch_us_timed_alone": pair_avg_s * 1e6,
+            "step_share": per_step[name] * avg_s * 1e3 / res["ms_per_step"],
             "kernel_time_share": st["total_ms"] / total_ms if total_ms else None}
     breakdown = {k: round(v["total_ms"] / steps, 4) for k, v in sorted(rep.items())}
     return roof, breakdown

@@ -218,7 +218,8 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
-    if (const char *c = getenv("BERT_HIP_HOST_EVENT_SCOPE")) e->host_event_device_scope_ = strcmp(c, "device") == 0;
+    if (const char *c = getenv("BERT_HIP_GEMM2X")) e->gemm2x_ = strcmp(c, "0") != 0;
+    if (const char *c = getenv("BERT_HIP_GEMM2X_SKEW")) e->gemm2x_skew_ = atoi(c);
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
     auto T = [&](const std::string &n) { return mf.find(n); };
@@ -261,11 +262,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     }
     ok = ok && e->status_.alloc(16, err);
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
-    // busy_ orders passes of ONE device against each other (the shared workspace): a device-scope release is all it needs.  With
-    // the default system-scope fence every pass ended with the L2s written back and the next pass's first kernel started behind
-    // an invalidate — the all-layers kernel then re-fetched its 20 MB of weights into every XCD's L2 on every step: 780 us in the
-    // step against 720 us for the same launch repeated back to back (round 4, rocprofv3 + bench.py's replay groups).
-    if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
+    if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
     if (!ok) { delete e; return nullptr; }
     return e;
 }
@@ -313,17 +310,12 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
+    else if (key == "gemm2x") gemm2x_ = value != "0";
+    else if (key == "gemm2x_skew") gemm2x_skew_ = atoi(value.c_str());
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
-    else if (key == "host_event_scope") {
-        // "device": the host path's chunk-done events skip the system-scope fence too (the embeddings go to pinned, fine-grained
-        // host memory straight from the kernel; the event only has to say that the pass is over); "system" (default)
-        host_event_device_scope_ = value == "device";
-        for (auto &sl : slot_)
-            if (sl.done) { (void)hipEventDestroy(sl.done); sl.done = nullptr; }
-    }
     else if (key == "profile_replay") {
         // "<kernel name>:<K>" (see timed()), "" switches back to an event pair per launch
         const size_t c = value.rfind(':');
@@ -346,7 +338,7 @@ void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
     auto get = [&]() {
         hipEvent_t ev;
         if (!ev_pool_.empty()) { ev = ev_pool_.back(); ev_pool_.pop_back(); }
-        else (void)hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);     // (timing only: no cache write-back / invalidate around the timed launch)
+        else (void)hipEventCreate(&ev);
         return ev;
     };
     if (!replay_name_.empty()) {
@@ -433,13 +425,16 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
 
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
                     half_t *C, int epi) {
-        const bool big = W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
-        const bool tiled = !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
+        // two 4-wave workgroups per CU (gemm2x.hip) where the shape allows it and the option is on, else one 8-wave workgroup
+        const bool two = W.mfma_ok && gemm2x_ && gemm256_ && !gemm_naive_ && gemm2x_supported(W.w, t_pad);
+        const bool big = !two && W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
+        const bool tiled = !two && !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
         // (which kernel family served the mat-mul: reported as "family:<kernel>_<weights>" lines of the profile)
         if (profiling_ && replay_name_.empty())
-            families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
+            families_[std::string("family:") + (two ? "gemm2x" : big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (two || big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (two) launch_gemm2x(W.w, A, bias, resid, C, t_pad, epi, s, gemm2x_skew_);
+            else if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
@@ -619,7 +614,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         if (sl.h_out_cap != out_cap || !sl.d_out_host)
             HIP_OK(hipHostGetDevicePointer((void **)&sl.d_out_host, sl.h_out, 0), err, -1);
         if (!sl.d_in.ensure(in_bytes, err) || (d_embeddings && !sl.d_out.ensure(max_nb * H * 4, err))) return -1;
-        if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | (host_event_device_scope_ ? hipEventDisableSystemFence : 0)), err, -1);
+        if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
     }
     if (!ensure_workspace((int)((max_T + 255) / 256 * 256), (int)max_nb, err)) return -1;
 

@@ -82,6 +82,11 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
 bool gemm256_supported(const GemmWeight &W, int M_pad);
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
                     int epilogue, hipStream_t stream);
+// Two independent 4-wave workgroups per CU, 256 x 128 x 32 tiles (gemm2x.hip): same operation and bits as gemm256; f16 images,
+// N % 128 == 0, K % 96 == 0, M_pad % 256 == 0.  skew_override >= 0: the second workgroup's start delay in units of 64 cycles.
+bool gemm2x_supported(const GemmWeight &W, int M_pad);
+void launch_gemm2x(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
+                   int epilogue, hipStream_t stream, int skew_override = -1);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
@@ -181,11 +186,10 @@ inline void configure_once(DeviceFlags &seen, F &&opt_in) {
 
 // Every kernel of the path is launched through BERT_LAUNCH.  While the engine profiles (Engine::timed) the launching thread
 // points tl_launch_timing at an event pair and the launch goes through hipExtLaunchKernelGGL, which attaches the events to the
-// dispatch itself (no hipEventRecord barrier packets of their own in the stream).  Measured (round 4): a launch timed this
-// way still runs with system-scope fences — L2 written back and invalidated around it — so a sub-millisecond kernel that lives
-// on L2-resident weights reads 5-8 % long (model_kernel 841 us against 777 us in rocprofv3's trace); for kernels of a
-// millisecond and more the two agree within 1 %.  These times feed the per-kernel BREAKDOWN; the roofline's kernel time comes
-// from the replay form (engine.hip timed(): K launches between one event pair).
+// dispatch itself (no hipEventRecord barrier packets of their own in the stream).  Measured (round 4): a launch timed alone
+// still reads long — model_kernel 825-866 us against 780 us in rocprofv3's trace of the same steps — whatever the events'
+// fence flags; for kernels of a millisecond and more the two agree within 1 %.  These times feed the per-kernel BREAKDOWN; the
+// roofline's kernel time comes from replay groups (engine.hip timed(), bench.py kernel_roofline).
 struct LaunchTiming { hipEvent_t start, stop; };
 inline thread_local const LaunchTiming *tl_launch_timing = nullptr;
 #define BERT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                     \
