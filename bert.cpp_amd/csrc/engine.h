@@ -116,8 +116,6 @@ private:
     bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
-    bool gemm2x_ = false;                        // "gemm2x": two 4-wave workgroups per CU for the H > 384 mat-muls (gemm2x.hip)
-    int gemm2x_skew_ = -1;                       // start delay of a CU's second workgroup (-1: half an output tile)
 
     // profiling
     bool profiling_ = false;

@@ -218,8 +218,6 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
-    if (const char *c = getenv("BERT_HIP_GEMM2X")) e->gemm2x_ = strcmp(c, "0") != 0;
-    if (const char *c = getenv("BERT_HIP_GEMM2X_SKEW")) e->gemm2x_skew_ = atoi(c);
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
     auto T = [&](const std::string &n) { return mf.find(n); };
@@ -310,8 +308,6 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
-    else if (key == "gemm2x") gemm2x_ = value != "0";
-    else if (key == "gemm2x_skew") gemm2x_skew_ = atoi(value.c_str());
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
@@ -425,16 +421,13 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
 
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
                     half_t *C, int epi) {
-        // two 4-wave workgroups per CU (gemm2x.hip) where the shape allows it and the option is on, else one 8-wave workgroup
-        const bool two = W.mfma_ok && gemm2x_ && gemm256_ && !gemm_naive_ && gemm2x_supported(W.w, t_pad);
-        const bool big = !two && W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
-        const bool tiled = !two && !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
+        const bool big = W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
+        const bool tiled = !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
         // (which kernel family served the mat-mul: reported as "family:<kernel>_<weights>" lines of the profile)
         if (profiling_ && replay_name_.empty())
-            families_[std::string("family:") + (two ? "gemm2x" : big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (two || big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
+            families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (two) launch_gemm2x(W.w, A, bias, resid, C, t_pad, epi, s, gemm2x_skew_);
-            else if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });

@@ -82,11 +82,6 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
 bool gemm256_supported(const GemmWeight &W, int M_pad);
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
                     int epilogue, hipStream_t stream);
-// Two independent 4-wave workgroups per CU, 256 x 128 x 32 tiles (gemm2x.hip): same operation and bits as gemm256; f16 images,
-// N % 128 == 0, K % 96 == 0, M_pad % 256 == 0.  skew_override >= 0: the second workgroup's start delay in units of 64 cycles.
-bool gemm2x_supported(const GemmWeight &W, int M_pad);
-void launch_gemm2x(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                   int epilogue, hipStream_t stream, int skew_override = -1);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);

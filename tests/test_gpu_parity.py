@@ -41,7 +41,7 @@ def _gelu(x):
     return 0.5 * x * (1 + np.tanh(0.7978845608028654 * x * (1 + 0.044715 * x * x)))
 
 
-@pytest.mark.parametrize("impl", [0, 1, 3, 4], ids=["mfma", "naive", "tile256", "tile2x"])
+@pytest.mark.parametrize("impl", [0, 1, 3], ids=["mfma", "naive", "tile256"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0", "q4_1", "f32"])
 @pytest.mark.parametrize("shape", [(200, 192, 128), (256, 384, 384), (130, 64, 64), (512, 1536, 384), (384, 384, 1536),
                                    (256, 1152, 384), (129, 2304, 768), (300, 768, 3072), (513, 3072, 768), (256, 256, 64)])
@@ -62,7 +62,7 @@ def test_gemm_kernel(impl, ftype, shape):
         try:
             got = pybert.test_gemm(A, wb, WT[ftype], N, bias, resid if epi == 2 else None, epi, impl).astype(np.float64)
         except RuntimeError as e:
-            if impl >= 3 and "-2" in str(e):
+            if impl == 3 and "-2" in str(e):
                 pytest.skip("shape / weight type not handled by this kernel")
             raise
         err = np.abs(got - want)
@@ -71,9 +71,8 @@ def test_gemm_kernel(impl, ftype, shape):
         assert not bad.any(), (ftype, shape, epi, impl, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5])
 
 
-@pytest.mark.parametrize("impl", [3, 4], ids=["tile256", "tile2x"])
 @pytest.mark.parametrize("M,N,K", [(20480, 2304, 768), (33000, 768, 3072), (70000, 768, 768), (20000, 3072, 768), (16640, 1536, 384)])
-def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl):
+def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
     """The 256 x 256 tile kernel runs one persistent workgroup per CU: with more output tiles than CUs a workgroup streams
     its reduction tiles across output tiles and finishes a tile's epilogue behind the next tile's first barrier.
     All three epilogues against numpy (float32 BLAS here: the product is too large for a float64 matmul in a test)."""
@@ -91,30 +90,6 @@ def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl):
         err = np.abs(got - want)
         bad = err > 2e-3 * np.abs(want) + 4e-3
         assert not bad.any(), (impl, epi, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (512, 2304, 768), (257, 768, 3072), (20480, 3072, 768), (33000, 768, 3072), (70000, 768, 768), (600, 128, 96)])
-def test_gemm2x_gives_gemm256_s_bits(M, N, K):
-    """gemm2x.hip (two independent 4-wave workgroups per CU, 256 x 128 x 32 tiles, three stages) performs gemm256's arithmetic:
-    the same MFMA sequence over k ascending from the same initial accumulators, the same epilogue — EQUAL BITS, all three
-    epilogues, from one output tile per workgroup to dozens (stream of stages across output tiles, feature-tile groups)."""
-    rng = np.random.default_rng(M + N + K)
-    A = rng.normal(0, 1, (M, K)).astype(np.float16)
-    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float16)
-    W[:, : K // 2] *= 1.5
-    W[: N // 3] += 0.02
-    bias = rng.normal(0, 0.5, N).astype(np.float32)
-    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
-    base = A.astype(np.float32) @ W.astype(np.float32).T + bias
-    for epi in (0, 1, 2):
-        r = resid if epi == 2 else None
-        got = pybert.test_gemm(A, W.view(np.uint8).reshape(-1), 1, N, bias, r, epi, 4)
-        if N % 256 == 0 and K >= 128:
-            want = pybert.test_gemm(A, W.view(np.uint8).reshape(-1), 1, N, bias, r, epi, 3)
-            assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (epi, int((got != want).sum()), np.argwhere(got != want)[:5].tolist())
-        ref = base if epi == 0 else _gelu(base.astype(np.float64)).astype(np.float32) if epi == 1 else base + resid.astype(np.float32)
-        err = np.abs(got.astype(np.float32) - ref)
-        assert not (err > 2e-3 * np.abs(ref) + 4e-3).any(), (epi, float(err.max()), np.argwhere(err > 2e-3 * np.abs(ref) + 4e-3)[:5].tolist())
 
 
 @pytest.mark.parametrize("wtype", [2, 3], ids=["q4_0", "q4_1"])
