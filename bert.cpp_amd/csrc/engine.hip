@@ -217,7 +217,6 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     }
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
-    if (const char *c = getenv("BERT_HIP_RESID_STREAM")) e->resid_stream_ = strcmp(c, "0") != 0;      // (tuning: A/B runs of gemm256's residual form)
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -258,12 +257,6 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
-    }
-    if (ok && mf.hp.n_embd > 384) {
-        // the 256 x 256 identity matrix gemm256's residual form multiplies the residual tile with (gemm256.hip, RS)
-        std::vector<_Float16> id((size_t)256 * 256, (_Float16)0);
-        for (int i = 0; i < 256; ++i) id[(size_t)i * 256 + i] = (_Float16)1;
-        ok = e->ident256_.upload(id.data(), id.size() * 2, err);
     }
     ok = ok && e->status_.alloc(16, err);
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
@@ -315,7 +308,6 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
-    else if (key == "resid_stream") resid_stream_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
@@ -435,7 +427,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         if (profiling_ && replay_name_.empty())
             families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s, resid_stream_ ? ident256_.as<half_t>() : nullptr);
+            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });

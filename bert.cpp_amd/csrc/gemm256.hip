@@ -54,7 +54,6 @@ struct Gemm256Args {
     half_t *C;              // [M_pad][N]
     const uint4 *qs;        // q4 forms: nibble plane / scale plane of W (kernels.h GemmWeight), w16 unused
     const void *sc;
-    const half_t *ident;    // RS forms: the 256 x 256 f16 identity matrix (see the kernel's comment)
     int N, K, n_tiles_n, n_tiles;
     int n_groups;           // feature-tile groups an XCD pair / quad shares the walk with (1: every XCD walks all feature tiles)
 };
@@ -123,25 +122,16 @@ __device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
 // packed f16 math applies (q - 8) d or q d + m: ~15 VALU + one ds_write_b128 per chunk), into the stage the f16 form fills by
 // LDS-DMA — the activation half still arrives that way.  At an output-tile boundary the pending block is expanded in one go in
 // front of the finished tile's epilogue, so the raw registers are dead while the epilogue needs every register.
-// RS = 1 (EPI_BIAS_RESID, f16 image): the RESIDUAL travels through the tile stream.  An output tile's stream starts with four
-// extra reduction tiles whose activation half is the residual tile R[256 tokens][64 features] (rows of `resid`, stride N) and
-// whose weight half is the matching [256 x 64] slice of the 256 x 256 identity matrix: acc = bias, then acc += R * I = bias + r
-// exactly (one non-zero product per element), then the reduction proper — the sum the RS = 0 form starts from, by another route.
-// What it replaces: 32 scattered 8-byte loads per lane and tile in the accumulator layout (32 cache lines per instruction:
-// 8-9 us of issue per tile) and 64 registers of residual values alive across the tile boundary; what it costs: four tiles of
-// 1.45 us on mostly-zero operands.  The epilogue is the bias form's.
-template <int EPI, int WT, int RS>
+template <int EPI, int WT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q4 = WT != GW_F16;
-    static_assert(!RS || (EPI == EPI_BIAS_RESID && !Q4), "residual stages: the f16 form of the residual epilogue");
-    constexpr bool RV = EPI == EPI_BIAS_RESID && !RS;       // the residual as initial accumulator values (loaded in the epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wf = wave & 1, wq = wave >> 1;         // feature half (128) / token quarter (64) of the tile
     const int l31 = lane & 31, hi = lane >> 5;
-    const int K = p.K, nk = K / G2_BK, nkt = nk + 4 * RS;     // reduction tiles of an output tile's stream
+    const int K = p.K, nk = K / G2_BK;
 
     // ---- this workgroup's output tiles: t_first, t_first + S, ... below t_end, in the XCD's own numbering.  An XCD walks a
     // contiguous range of token tiles and, of each, the feature tiles n_begin .. n_begin + cnt_n back to back (an activation
@@ -166,30 +156,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     if (tile >= t_end) return;
 
     // ---- LDS-DMA: a reduction tile is 2 x 32 pieces of 1 KiB (8 rows each), 4 + 4 per wave; source offsets (elements)
-    unsigned doff[4], doffN[RS ? 4 : 1], doffI[RS ? 4 : 1];     // row strides K (activations, weights), N (residual), 256 (identity)
+    unsigned doff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (wave * 4 + i) * 8 + (lane >> 3);
-        const int c8 = ((lane & 7) ^ ((r >> 1) & 7)) << 3;
-        doff[i] = (unsigned)(r * K + c8);
-        if constexpr (RS) { doffN[i] = (unsigned)(r * p.N + c8); doffI[i] = (unsigned)(r * 256 + c8); }
+        doff[i] = (unsigned)(r * K + (((lane & 7) ^ ((r >> 1) & 7)) << 3));
     }
-    // the sources of reduction tile q of the output tile at (tm0, tn0)
-    struct StageSrc { const half_t *a, *w; bool ident; };
-    auto stage_src = [&](int tm0, int tn0, int q) __attribute__((always_inline)) {
-        if constexpr (RS)
-            if (q < 4) return StageSrc{p.resid + (size_t)tm0 * p.N + tn0 + q * G2_BK, p.ident + q * G2_BK, true};
-        const int kt = q - 4 * RS;
-        return StageSrc{p.A + (size_t)tm0 * K + kt * G2_BK, p.w16 + (size_t)tn0 * K + kt * G2_BK, false};
-    };
-    auto dma_piece = [&](const StageSrc &src, char *stage_base, auto i_tag) __attribute__((always_inline)) {
+    auto dma_piece = [&](const half_t *src, char *stage_base, auto i_tag) __attribute__((always_inline)) {
         constexpr int i = decltype(i_tag)::value;       // 0..3: activation pieces, 4..7: weight pieces
         if constexpr (Q4 && i >= 4) return;             // (q4: the weight half is expanded from blocks, below)
-        else {
-            unsigned off = doff[i & 3];
-            if constexpr (RS) off = src.ident ? (i < 4 ? doffN[i & 3] : doffI[i & 3]) : off;
-            __builtin_amdgcn_global_load_lds(G2_GLOBAL((i < 4 ? src.a : src.w) + off), G2_LDS(stage_base + (i >> 2) * G2_TILE + (wave * 4 + (i & 3)) * 1024), 16, 0, 0);
-        }
+        else __builtin_amdgcn_global_load_lds(G2_GLOBAL(src + doff[i & 3]), G2_LDS(stage_base + (i >> 2) * G2_TILE + (wave * 4 + (i & 3)) * 1024), 16, 0, 0);
     };
 
     // ---- fragment addresses of the four k-steps of a reduction tile (stage 0; the other stage is address ^ 64 KiB)
@@ -294,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // lines per instruction — 8-9 us of a 35 us tile go into their issue wherever they are placed; fetching the tile in
     // 16-byte row segments and turning it through the staging area was tried: the register allocator spills all sixteen
     // vectors in front of the stores, and landing them by LDS-DMA has to wait behind the stores round by round).
-    f16x4 rv[RV ? 4 : 1][2][4];
+    f16x4 rv[EPI == EPI_BIAS_RESID ? 4 : 1][2][4];
     auto init_loads = [&](int im0, int in0) __attribute__((always_inline)) {
         int l31 = lane & 31, hi = lane >> 5;
         asm volatile("" : "+v"(l31), "+v"(hi));
@@ -306,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = b[e];
             }
-        if (RV && !(G2_ABLATE & 4)) {
+        if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const half_t *rrow = p.resid + ((size_t)im0 + wq * 64 + j * 32 + l31) * p.N + in0 + wf * 128 + 4 * hi;
@@ -325,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float b = acc[i][0][4 * g + e];
-                    if (RV && !(G2_ABLATE & 4)) {
+                    if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
                         acc[i][1][4 * g + e] = b + (float)rv[i][1][g][e];
                         acc[i][0][4 * g + e] = b + (float)rv[i][0][g][e];
                     } else {
@@ -433,9 +409,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // tools/ubench/store_issue.hip — not the other CUs' bursts)
     int m0 = (tile / cnt_n) * G2_BM, n0 = (n_begin + tile % cnt_n) * G2_BN;
     {   // the first reduction tile of the first output tile
-        const StageSrc s0 = stage_src(m0, n0, 0);
-        dma_piece(s0, smem, I0{}); dma_piece(s0, smem, I1{}); dma_piece(s0, smem, I2{}); dma_piece(s0, smem, I3{});
-        dma_piece(s0, smem, I4{}); dma_piece(s0, smem, I5{}); dma_piece(s0, smem, I6{}); dma_piece(s0, smem, I7{});
+        const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
+        dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
+        dma_piece(w, smem, I4{}); dma_piece(w, smem, I5{}); dma_piece(w, smem, I6{}); dma_piece(w, smem, I7{});
         if constexpr (Q4) {
             q4_request(n0, 0);
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_q), "+v"(raw_sc) : : "memory");
@@ -451,9 +427,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // k-steps 0..2 of a reduction tile whose first fragments (f0) have been requested; leaves the last k-step's fragments
     // (f1) in flight: its MFMAs run after the next barrier.  Then the fragment addresses move to the other stage.
     // the pieces of the next reduction tile that G2_DMA_PLAN puts into `step`, each behind its MFMA
-    auto dma_fill = [&](const StageSrc &ns, char *nstage, auto step_tag, auto m_tag) __attribute__((always_inline)) {
+    auto dma_fill = [&](const half_t *na, const half_t *nw, char *nstage, auto step_tag, auto m_tag) __attribute__((always_inline)) {
         constexpr int piece = g2_piece_at(decltype(step_tag)::value, decltype(m_tag)::value);
-        if constexpr (piece >= 0) dma_piece(ns, nstage, std::integral_constant<int, (piece >= 0 ? piece : 0)>{});
+        if constexpr (piece >= 0) dma_piece(piece < 4 ? na : nw, nstage, std::integral_constant<int, (piece >= 0 ? piece : 0)>{});
     };
     // q4 (`expand`: the pending block has not been expanded in one go at the top of the period): chunks 0, 1 behind MFMAs 1, 5
     // of k-step 0, chunks 2, 3 behind MFMAs 1, 5 of k-step 1; the block of the tile after next (rn0, rkt) is requested behind
@@ -466,14 +442,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             if constexpr (step == 3 && m == 1) q4_request(rn0, rkt);
         }
     };
-    auto steps_0_to_2 = [&](const StageSrc &ns, char *nstage, auto expand_tag, int rn0, int rkt) __attribute__((always_inline)) {
+    auto steps_0_to_2 = [&](const half_t *na, const half_t *nw, char *nstage, auto expand_tag, int rn0, int rkt) __attribute__((always_inline)) {
         const unsigned nxor = (unsigned)(nstage - smem);
         read_frag(f1, I1{}); g2_wait6(f0);
-        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(ns, nstage, I1{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I1{}, m); });
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I1{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I1{}, m); });
         read_frag(f0, I2{}); g2_wait6(f1);
-        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(ns, nstage, I2{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I2{}, m); });
+        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I2{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I2{}, m); });
         read_frag(f1, I3{}); g2_wait6(f0);
-        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(ns, nstage, I3{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I3{}, m); });
+        mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I3{}, m); q4_fill(expand_tag, nxor, rn0, rkt, I3{}, m); });
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { aA[kk] ^= (unsigned)G2_STAGE; aW[kk] ^= (unsigned)G2_STAGE; }
     };
@@ -484,14 +460,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         // (after the last output tile the stream requests this tile's first reduction tile once more: a request that
         // is never read costs less than a branch around every request)
         const int nm0 = more ? (next / cnt_n) * G2_BM : m0, nn0 = more ? (n_begin + next % cnt_n) * G2_BN : n0;
+        const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
         {   // ---- reduction tile 0: the previous output tile is finished behind its barrier
             tile_barrier(f1);
-            const StageSrc ns = stage_src(m0, n0, 1);
+            const half_t *na = ta + G2_BK, *nw = tw + G2_BK;
             char *nstage = smem + (stage ^ 1) * G2_STAGE;
             // (this tile's step-0 pieces go out in one go: with a previous output tile its last k-step and epilogue follow,
             // without one there is nothing to put them between)
             static_for<g2_plan_count(0)>([&](auto i) __attribute__((always_inline)) {
-                dma_piece(ns, nstage, i);
+                constexpr int piece = decltype(i)::value;
+                dma_piece(piece < 4 ? na : nw, nstage, i);
             });
             // (q4: this output tile's second weight tile, in one go — its registers must be free during the epilogue)
             if constexpr (Q4) q4_expand_all((unsigned)(nstage - smem));
@@ -501,18 +479,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                 init_acc();
             }
             read_frag(f0, I0{});
-            steps_0_to_2(ns, nstage, std::false_type{}, nk > 2 ? n0 : nn0, nk > 2 ? 2 : 0);
+            steps_0_to_2(na, nw, nstage, std::false_type{}, nk > 2 ? n0 : nn0, nk > 2 ? 2 : 0);
             stage ^= 1;
         }
-        for (int kt = 1; kt < nkt; ++kt) {             // (kt: the position in the output tile's stream; RS = 0: the reduction tile)
+        for (int kt = 1; kt < nk; ++kt) {
             tile_barrier(f1);
             // the next reduction tile (of this output tile, or the first of the next one) into the stage just released
-            const StageSrc ns = kt + 1 == nkt ? stage_src(nm0, nn0, 0) : stage_src(m0, n0, kt + 1);
+            const bool last = kt + 1 == nk;
+            const half_t *na = last ? p.A + (size_t)nm0 * K : ta + (kt + 1) * G2_BK;
+            const half_t *nw = last ? p.w16 + (size_t)nn0 * K : tw + (kt + 1) * G2_BK;
             char *nstage = smem + (stage ^ 1) * G2_STAGE;
             read_frag(f0, I0{});
             // the previous reduction tile's last k-step, with the new tile's first requests between its MFMAs
-            mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(ns, nstage, I0{}, m); });
-            steps_0_to_2(ns, nstage, std::true_type{}, kt + 2 < nk ? n0 : nn0, kt + 2 < nk ? kt + 2 : kt + 2 - nk);
+            mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill(na, nw, nstage, I0{}, m); });
+            steps_0_to_2(na, nw, nstage, std::true_type{}, kt + 2 < nk ? n0 : nn0, kt + 2 < nk ? kt + 2 : kt + 2 - nk);
             stage ^= 1;
         }
         have_prev = true; pm0 = m0; pn0 = n0;
@@ -530,9 +510,9 @@ bool gemm256_supported(const GemmWeight &W, int M_pad) {
 }
 
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream, const half_t *ident) {
+                    int epilogue, hipStream_t stream) {
     Gemm256Args a;
-    a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C; a.qs = W.qs; a.sc = W.sc; a.ident = ident;
+    a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C; a.qs = W.qs; a.sc = W.sc;
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
     a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
     // feature groups: only where W (N x K f16) overflows an XCD's L2 share and reading the activations twice is the cheaper
@@ -552,7 +532,7 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
     const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
-    static DeviceFlags configured[10];
+    static DeviceFlags configured[9];
     auto go = [&](auto kernel, int e) {
         configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
@@ -560,15 +540,9 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     auto by_type = [&](auto epi_tag) {
         constexpr int E = decltype(epi_tag)::value;
         switch (W.type) {
-            case GW_F16:
-                if constexpr (E == EPI_BIAS_RESID) {
-                    // the residual through the tile stream (identity stages) when the caller brings the identity matrix
-                    if (ident && W.N % 8 == 0) { go(gemm256_kernel<E, GW_F16, 1>, 9); break; }
-                }
-                go(gemm256_kernel<E, GW_F16, 0>, E);
-                break;
-            case GW_Q4_0: go(gemm256_kernel<E, GW_Q4_0, 0>, 3 + E); break;
-            default: go(gemm256_kernel<E, GW_Q4_1, 0>, 6 + E); break;
+            case GW_F16: go(gemm256_kernel<E, GW_F16>, E); break;
+            case GW_Q4_0: go(gemm256_kernel<E, GW_Q4_0>, 3 + E); break;
+            default: go(gemm256_kernel<E, GW_Q4_1>, 6 + E); break;
         }
     };
     switch (epilogue) {

@@ -80,10 +80,8 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
                       int M_pad, int epilogue, hipStream_t stream);
 // Large-tile variant (gemm256.hip): 256 x 256 x 64 tiles, 8 waves; f16 weights, N % 256 == 0, M_pad % 256 == 0.
 bool gemm256_supported(const GemmWeight &W, int M_pad);
-// ident (optional): a 256 x 256 f16 identity matrix in device memory — the residual epilogue of f16 images then takes the
-// residual through the tile stream (gemm256.hip, RS form) instead of loading it in the accumulator layout.
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream, const half_t *ident = nullptr);
+                    int epilogue, hipStream_t stream);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);

@@ -32,7 +32,7 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     GemmWeightStore ws;
     if (!ws.build({&t}, impl == 1, err)) { fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str()); return -1; }
     if (impl != 1 && !ws.mfma_ok) { fprintf(stderr, "bert_hip_test_gemm: shape not supported by the MFMA path\n"); return -2; }
-    const int M_pad = (impl == 3 || impl == 5) ? (M + 255) / 256 * 256 : (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int M_pad = impl == 3 ? (M + 255) / 256 * 256 : (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
     DevBuf dA, dB, dR, dC;
     if (!dA.alloc((size_t)M_pad * K * 2, err) || !dC.alloc((size_t)M_pad * N * 2, err) || !dB.upload(bias, (size_t)N * 4, err)) {
         fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str());
@@ -43,16 +43,9 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
         if (!dR.alloc((size_t)M_pad * N * 2, err)) return -1;
         CK(hipMemcpy(dR.p, resid, (size_t)M * N * 2, hipMemcpyHostToDevice));
     }
-    if (impl == 3 || impl == 5) {            // 5: the residual through the tile stream (identity stages)
+    if (impl == 3) {
         if (!gemm256_supported(ws.w, M_pad)) return -2;
-        DevBuf dI;
-        if (impl == 5) {
-            std::vector<_Float16> id((size_t)256 * 256, (_Float16)0);
-            for (int i = 0; i < 256; ++i) id[(size_t)i * 256 + i] = (_Float16)1;
-            if (!dI.upload(id.data(), id.size() * 2, err)) return -1;
-        }
-        launch_gemm256(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr, impl == 5 ? dI.as<half_t>() : nullptr);
-        CK(hipDeviceSynchronize());
+        launch_gemm256(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     } else if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     else launch_gemm_naive(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M, epilogue, nullptr);
     CK(hipGetLastError());

@@ -92,32 +92,6 @@ def test_gemm_persistent_workgroups_walk_several_tiles(M, N, K, impl=3):
         assert not bad.any(), (impl, epi, int(bad.sum()), float(err.max()), np.argwhere(bad)[:5].tolist())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 768, 768), (257, 768, 3072), (33000, 768, 3072), (70000, 768, 768), (20000, 3072, 768), (9000, 256, 128)])
-def test_gemm256_residual_through_the_tile_stream(M, N, K):
-    """gemm256's residual epilogue, f16 image: the residual tile enters as four extra reduction tiles against slices of the
-    256 x 256 identity matrix (acc = bias + R * I, exact: one non-zero product per element) instead of being loaded in the
-    accumulator layout at the tile boundary.  The sum starts from the same value: EQUAL BITS with the loading form, and right
-    against numpy; one output tile per workgroup, dozens (identity stages requested across output-tile boundaries), K = 128."""
-    rng = np.random.default_rng(M + N + K + 1)
-    A = rng.normal(0, 1, (M, K)).astype(np.float16)
-    W = (rng.normal(0, 1, (N, K)) / np.sqrt(K)).astype(np.float16)
-    W[:, : K // 2] *= 1.5
-    W[: N // 3] += 0.02
-    bias = rng.normal(0, 0.5, N).astype(np.float32)
-    resid = rng.normal(0, 1, (M, N)).astype(np.float16)
-    resid[::7, ::5] = 0                          # (signed zeros, exact values, large ones: the identity product must reproduce them all)
-    resid[1::11, 3::13] = np.float16(-0.0)
-    resid[2::17, 1::3] = np.float16(60000.0)
-    resid[3::19, 2::7] = np.float16(6e-8)
-    got = pybert.test_gemm(A, W.view(np.uint8).reshape(-1), 1, N, bias, resid, 2, 5)
-    want = pybert.test_gemm(A, W.view(np.uint8).reshape(-1), 1, N, bias, resid, 2, 3)
-    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (int((got.view(np.uint16) != want.view(np.uint16)).sum()), np.argwhere(got.view(np.uint16) != want.view(np.uint16))[:5].tolist())
-    ref = A.astype(np.float32) @ W.astype(np.float32).T + bias + resid.astype(np.float32)
-    fin = np.isfinite(ref) & (np.abs(ref) < 60000)
-    err = np.abs(got.astype(np.float32) - ref)
-    assert not (err[fin] > 2e-3 * np.abs(ref[fin]) + 4e-3).any(), float(err[fin].max())
-
-
 @pytest.mark.parametrize("wtype", [2, 3], ids=["q4_0", "q4_1"])
 @pytest.mark.parametrize("M,N,K", [(300, 768, 768), (512, 2304, 768), (257, 768, 3072), (20480, 3072, 768), (33000, 768, 3072), (9000, 256, 128)])
 def test_gemm256_q4_tile_load_gives_the_f16_form_s_bits(M, N, K, wtype):
