@@ -276,26 +276,29 @@ __global__ __launch_bounds__(256) void layernorm_kernel(half_t *x, const float *
 }
 
 // The same for H % 8 == 0: a lane owns 16-byte runs of the row (one 16-byte load and store per 8 features; the two-byte-pair
-// form above moved 2.7 TB/s at H = 768), NC runs per lane (H <= 512 * NC).  Same arithmetic (two passes, eps 1e-5).
+// form above moved 2.7 TB/s at H = 768), NC runs per lane (H <= 512 * NC), every run of the row requested before the first is
+// touched.  Same arithmetic (two passes, eps 1e-5).  5.1 TB/s at H = 768 and 262 144 rows; two or four rows per wave (more
+// loads in flight per lane) measured 0 / +2 % time: the kernel is not short of requests.
 template <int NC>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(half_t *x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, int T, int H) {
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= T) return;
     half_t *row = x + (size_t)t * H;
-    float v[NC][8];
-    float sum = 0.f;
+    f16x8m h[NC];
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
         const int e0 = 8 * (lane + 64 * j);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[j][i] = 0.f;
-        if (e0 < H) {
-            const f16x8m h = *(const f16x8m *)(row + e0);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { v[j][i] = (float)h[i]; sum += v[j][i]; }
-        }
+        for (int i = 0; i < 8; ++i) h[j][i] = (_Float16)0.f;
+        if (e0 < H) h[j] = *(const f16x8m *)(row + e0);
     }
+    float v[NC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[j][i] = (float)h[j][i]; sum += v[j][i]; }
     const float mean = wave_sum(sum) / H;
     float sq = 0.f;
 #pragma unroll
