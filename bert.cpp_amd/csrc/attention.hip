@@ -41,7 +41,10 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
 // SLOWER than eight with 128-key steps; the counters of that shape: MFMA busy 27 %, VALU issue ~21 %, the rest waits.
 // Also measured there and dropped: two query blocks per wave pass sharing the K / V^T fragment reads (64-key steps, the
 // registers allow no more: 12 % slower; 128-key steps spill), and every fragment of a step requested ahead of its MFMAs
-// (3 % slower at 512 tokens; at 128 tokens the extra registers cost the third wave per SIMD: 15 % slower).)
+// (3 % slower at 512 tokens; at 128 tokens the extra registers cost the third wave per SIMD: 15 % slower).  Round 4, same
+// shape, replay groups of 20 launches: static priority for waves 4-7 (697 against 698-704 us: nothing), the V fragments of a
+// chunk requested in front of its softmax (+0.4 %), the output rescale skipped behind a ballot while no query's maximum grows
+// by more than 2^8 (+2.7 %: the branch costs more than the 32 multiplies).)
 template <int D, int NT, int CH>
 __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__restrict__ qkv,
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,

@@ -44,7 +44,8 @@ for k in ("model_kernel", "layer_tail", "qkv_attention2"):
         busy[k] = (m, gui, m / (1024 * gui))
     except StopIteration:
         pass
-bench = json.loads(read(f"bench_{tag}.log"))
+bench_text = [l for l in read(f"bench_{tag}.log").splitlines() if l.startswith("{")][-1]      # (RCCL prints its banner to stdout too)
+bench = json.loads(bench_text)
 hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
        f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers: ONE launch for all layers (model_kernel: a workgroup per window, qkv_attention2 + layer_tail as phases)\n"
        f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), its own time of {bench['roofline']['kernel']} ({bench['roofline']['timing']}): {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
@@ -65,7 +66,14 @@ with open(os.path.join(P, f"{tag}_pmc.txt"), "w") as f:
 with open(os.path.join(P, "traffic.json"), "w") as f:
     f.write(read(f"traffic_{tag}.json"))
 with open(os.path.join(P, f"{tag}_bench_line.json"), "w") as f:
-    f.write(read(f"bench_{tag}.log"))
+    f.write(bench_text + "\n")
+# the line the bench printed UNDER rocprofv3 (the process whose kernel trace is {tag}_kernel_stats.txt): like with like
+prof_line = read(f"bench_prof_line_{tag}.txt").strip()
+if prof_line.startswith("{"):
+    with open(os.path.join(P, f"{tag}_bench_line_profiled.json"), "w") as f:
+        f.write(prof_line + "\n")
+    pl = json.loads(prof_line)
+    print("under rocprofv3:", round(pl["value"]), "sentences/s,", pl["roofline"]["kernel"], round(pl["roofline"]["avg_launch_us"], 1), "us per launch (", pl["roofline"]["timing"][:60], "...)")
 cal = [l for l in read(f"gemm_calibration_{tag}.txt").splitlines() if "amdgpu.ids" not in l]
 with open(os.path.join(P, f"{tag}_gemm_calibration.txt"), "w") as f:
     f.write(f"# python tools/gemm_calibration.py on the box of this round check (commit {commit}): torch.matmul = hipBLASLt (Custom_Cijk_..._MT256x256x64_MI16x16x1 on the bert-base shapes), f16 in, f16 out, NO bias / GELU / residual;\n"
