@@ -46,7 +46,7 @@ for k in ("model_kernel", "layer_tail", "qkv_attention2"):
         pass
 bench_text = [l for l in read(f"bench_{tag}.log").splitlines() if l.startswith("{")][-1]      # (RCCL prints its banner to stdout too)
 bench = json.loads(bench_text)
-hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
+hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
        f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers: ONE launch for all layers (model_kernel: a workgroup per window, qkv_attention2 + layer_tail as phases)\n"
        f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), its own time of {bench['roofline']['kernel']} ({bench['roofline']['timing']}): {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
        "# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): " +

@@ -16,7 +16,9 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 timeout 900 python bench.py > $OUT/bench_$TAG.log 2> $OUT/bench_$TAG.err; echo "bench rc=$?"; cut -c1-600 $OUT/bench_$TAG.log
 
 cd /tmp
-B1="python $OUT/../bench.py --steps 10 --warmup 3 --repeat 2 --no-cpu-baseline --also"
+# (100-step regions like the un-profiled line: a region's fixed costs — first launch, final synchronisation, the profiler's flush —
+# spread over 10 steps would inflate ms_per_step, which the in-place kernel's roofline time is derived from)
+B1="python $OUT/../bench.py --steps 100 --warmup 10 --repeat 2 --no-cpu-baseline --also"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats_$TAG -o stats -- $B1 > $OUT/bench_prof_$TAG.log 2>&1; echo "stats rc=$?"
 B3="python $OUT/../bench.py --config 3 --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --also"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats3_$TAG -o stats -- $B3 > $OUT/bench_prof3_$TAG.log 2>&1; echo "stats3 rc=$?"
