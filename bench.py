@@ -279,6 +279,8 @@ def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
         avg_s = (res["ms_per_step"] - others_ms) * 1e-3 / per_step[name]
         timing = (f"in-place kernel: step time ({res['ms_per_step']:.4f} ms) minus the replay-group times of the step's other kernels "
                   f"({', '.join(f'{k} {per_step[k]:g} x {t * 1e6:.1f} us' for k, t in sorted(others.items()))}), over {per_step[name]:g} launches per step")
+        if res["cfg"].get("host_step"):
+            timing += " — a host-paced step (staging, copies): the GPU idles in it, so this is an UPPER bound of the kernel's time (the device-resident entry of the same batch has the kernel's own)"
     else:
         avg_s, K, n = replay_avg(name, pair_avg_s)
         timing = f"{K} back-to-back launches between one HIP event pair on the launch stream, median of {n} such groups"
