@@ -102,7 +102,8 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
 
 /* Environment, read by bert_load_from_file (six switches):
  *   BERT_HIP_DEVICES       "all" or a comma-separated list of HIP ordinals without repeats: the GPUs of the context
- *                          (default: the calling thread's current device — one context, one GPU, unless asked otherwise)
+ *                          (default: the calling thread's current device — one context, one GPU, unless asked otherwise);
+ *                          BERT_HIP_DEVICE=<n>, the spelling of the first builds, is read as a list of one when this is unset
  *   BERT_HIP_KERNELS       "fused" (default): two launches per layer where the shape allows it — projection + attention of a
  *                          128-slot window (qkv_attention2.hip), everything behind the attention (layer_tail.hip) —, tiled kernels
  *                          elsewhere | "tiled": GEMM, attention and LayerNorm kernels only (Q|K|V and the intermediate through

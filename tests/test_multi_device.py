@@ -375,3 +375,23 @@ def test_multi_rank_path_with_the_hip_engine(make_model, tmp_path, world):
     ref = np.load(tmp_path / "ref.npy")
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"rank{r}.npy"), ref), r
+
+
+@pytest.mark.gpu
+def test_device_selection_environment(make_model, monkeypatch, capfd):
+    """BERT_HIP_DEVICES names the context's GPUs; BERT_HIP_DEVICE=<n> (the single-device spelling of the first builds) is read
+    as a list of one when BERT_HIP_DEVICES is unset; a bad ordinal fails the load loudly instead of landing on device 0."""
+    path, hp = make_model("tiny", "f16", 0)
+    monkeypatch.delenv("BERT_HIP_DEVICES", raising=False)
+    monkeypatch.setenv("BERT_HIP_DEVICE", "0")
+    m = pybert.BertModel(path)
+    assert m.n_devices() == 1 and m.lib.bert_hip_device(m.ctx) == 0
+    m.close()
+    monkeypatch.setenv("BERT_HIP_DEVICE", "63")
+    with pytest.raises(RuntimeError):
+        pybert.BertModel(path)
+    assert "out of range" in capfd.readouterr().err
+    monkeypatch.setenv("BERT_HIP_DEVICES", "0")          # (the list wins over the alias)
+    m = pybert.BertModel(path)
+    assert m.n_devices() == 1
+    m.close()
