@@ -203,7 +203,7 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
         torch.cuda.synchronize(device)
         assert hip.hipMemcpy(ctypes.c_void_p(host.ctypes.data), ctypes.c_void_p(gathered["ptr"]), ctypes.c_size_t(host.nbytes), 2) == 0
         out = torch.from_numpy(host)
-    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=out, steps=steps, regions=regions,
+    res = dict(cfg=cfg, cfg_id=cfg_id, hp=hp, model=model, path=path, flat=flat, cu=cu, out=out, steps=steps, regions=regions, world=world,
                value=world * B * steps / dt, ms_per_step=1e3 * dt / steps, step=step, tokens=T, max_len=max_len)
     return res
 
@@ -281,6 +281,8 @@ def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
                   f"({', '.join(f'{k} {per_step[k]:g} x {t * 1e6:.1f} us' for k, t in sorted(others.items()))}), over {per_step[name]:g} launches per step")
         if res["cfg"].get("host_step"):
             timing += " — a host-paced step (staging, copies): the GPU idles in it, so this is an UPPER bound of the kernel's time (the device-resident entry of the same batch has the kernel's own)"
+        if res.get("world", 1) > 1:
+            timing += " — the step ends with the RCCL all-gather of the embeddings, which this difference books on the kernel: an UPPER bound of its time"
     else:
         avg_s, K, n = replay_avg(name, pair_avg_s)
         timing = f"{K} back-to-back launches between one HIP event pair on the launch stream, median of {n} such groups"
@@ -451,7 +453,7 @@ def run_inproc(args):
         r = sorted(B * args.steps / np.asarray(regions))
         fps = flops_per_sentence(hp, cfg["seq_len"] or 25)
         # per-kernel HIP-event times of device 0 (every device runs the same launches on its shard)
-        res = dict(cfg=cfg, cfg_id=args.config, hp=hp, model=m, path=path, flat=ids, cu=cu, step=step, tokens=int(cu[-1]),
+        res = dict(cfg=dict(cfg, host_step=True), cfg_id=args.config, hp=hp, model=m, path=path, flat=ids, cu=cu, step=step, tokens=int(cu[-1]),
                    value=B * args.steps / dt, ms_per_step=1e3 * dt / args.steps, steps=args.steps, regions=regions)
         roof, bd = kernel_roofline(res, None, None, steps=3, sync=lambda: None)
         line = {
