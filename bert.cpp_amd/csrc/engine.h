@@ -95,7 +95,7 @@ private:
     std::vector<LayerWeights *> layers_;
 
     // workspace (grow-only)
-    DevBuf x_, qkv_, ctx_, y_, ff_, v32_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_, ln_scratch_;
+    DevBuf x_, qkv_, ctx_, y_, ff_, v32_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_;
     hipStream_t stream_ = nullptr;
     // the workspace serves ONE forward pass at a time: every pass waits for the previous one's event on its own stream
     hipEvent_t busy_ = nullptr;
@@ -116,7 +116,6 @@ private:
     bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
-    bool ln_fused_ = false;           // "ln_fused": gemm256's residual form carries the LayerNorm behind it (measured slower: off)
 
     // profiling
     bool profiling_ = false;

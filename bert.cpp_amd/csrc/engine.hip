@@ -217,7 +217,6 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     }
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
-    if (const char *c = getenv("BERT_HIP_LN_FUSED")) e->ln_fused_ = strcmp(c, "0") != 0;      // (tuning: A/B runs)
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
@@ -309,7 +308,6 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
-    else if (key == "ln_fused") ln_fused_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
@@ -326,7 +324,7 @@ bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
     return x_.ensure(tp * H * 2, err) && qkv_.ensure(tp * 3 * H * 2, err) && ctx_.ensure(tp * H * 2, err) &&
            y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && v32_.ensure((size_t)128 * H * 4, err) &&
-           d_out_.ensure((size_t)n_sentences * H * 4, err) && ln_scratch_.ensure(H > 384 ? tp * 16 : 16, err) &&
+           d_out_.ensure((size_t)n_sentences * H * 4, err) &&
            windows_.ensure((size_t)n_sentences * sizeof(int2), err);
 }
 
@@ -422,21 +420,17 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const double Td = (double)T;
 
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
-                    half_t *C, int epi, const float *ln_g = nullptr, const float *ln_b = nullptr) {
+                    half_t *C, int epi) {
         const bool big = W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
-        const bool ln_inside = epi == EPI_BIAS_RESID_LN && big && ln_fused_ && gemm256_ln_supported(W.w, t_pad);
-        const bool ln_behind = epi == EPI_BIAS_RESID_LN && !ln_inside;
-        if (ln_behind) epi = EPI_BIAS_RESID;
         const bool tiled = !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
         // (which kernel family served the mat-mul: reported as "family:<kernel>_<weights>" lines of the profile)
         if (profiling_ && replay_name_.empty())
             families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s, ln_g, ln_b, ln_scratch_.p);
+            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
-        if (ln_behind) timed("layernorm", 0.0, s, [&] { launch_layernorm(C, ln_g, ln_b, T, H, s); });
     };
     auto tap = [&](int idx) {
         if (d_hidden) launch_f16_to_f32(x, d_hidden + (size_t)idx * T * H, (size_t)T * H, s);
@@ -557,9 +551,11 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                                   L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), x, t_pad, s);
             });
         } else {
-            gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID_LN, L.ln_att_w.as<float>(), L.ln_att_b.as<float>());
+            gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
+            timed("layernorm", 0.0, s, [&] { launch_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
             gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
-            gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID_LN, L.ln_out_w.as<float>(), L.ln_out_b.as<float>());
+            gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
+            timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
         }
         tap(il + 1);
     }

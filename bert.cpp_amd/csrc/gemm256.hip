@@ -54,8 +54,6 @@ struct Gemm256Args {
     half_t *C;              // [M_pad][N]
     const uint4 *qs;        // q4 forms: nibble plane / scale plane of W (kernels.h GemmWeight), w16 unused
     const void *sc;
-    const float *gamma, *beta;   // LN form: the LayerNorm behind the residual mat-mul (reference bert.cpp:866-875, 892-901)
-    float2 *ln_scratch;          // LN form: [M_pad][2] partial (sum, sum of squares) of a row per feature half of the tiles
     int N, K, n_tiles_n, n_tiles;
     int n_groups;           // feature-tile groups an XCD pair / quad shares the walk with (1: every XCD walks all feature tiles)
 };
@@ -124,19 +122,10 @@ __device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
 // packed f16 math applies (q - 8) d or q d + m: ~15 VALU + one ds_write_b128 per chunk), into the stage the f16 form fills by
 // LDS-DMA — the activation half still arrives that way.  At an output-tile boundary the pending block is expanded in one go in
 // front of the finished tile's epilogue, so the raw registers are dead while the epilogue needs every register.
-// EPI_BIAS_RESID_LN (round 4, measured slower and removed again — see DESIGN.md section 3): the residual mat-mul AND the LayerNorm
-// behind it (N = H <= 1024: a row is at most four tiles wide).  A workgroup takes ALL feature tiles of a token tile, back to
-// back; every tile's epilogue adds the lane's share of the rows' (sum, sum of squares) over the rounded outputs; the LAST tile's
-// epilogue completes the statistics (the two feature halves of the tiles live in different waves: one exchange through
-// `ln_scratch` in global memory — the LDS is full — behind a workgroup barrier), normalises its own tile in registers before it
-// is stored, and then FIXES UP the earlier tiles of the row: its own 64 tokens x 128 features of each, read back as 16-byte row
-// segments, normalised, stored again.
 template <int EPI, int WT>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q4 = WT != GW_F16;
-    constexpr bool LN = EPI == EPI_BIAS_RESID_LN;
-    constexpr bool RV = EPI == EPI_BIAS_RESID || LN;        // the residual as part of the accumulators' initial value
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,22 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         t_end = t_begin + (q + (r < rem ? 1 : 0)) * cnt_n;
     }
     int tile = t_begin + (int)(blockIdx.x >> 3);
-    // LN form: the XCD's range is cut at TOKEN tiles; workgroup j of the XCD takes token tiles tb + j, tb + j + S, ... and of
-    // each the nf feature tiles in a row: `tile` counts the workgroup's own output tiles (token tile tile / nf, feature tile % nf)
-    const int nf = p.n_tiles_n;
-    int tb = 0;
-    if constexpr (LN) {
-        const int tm = p.n_tiles / nf, q8 = tm >> 3, r8 = tm & 7;
-        tb = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-        const int te = tb + q8 + (xcd < r8 ? 1 : 0), first = tb + (int)(blockIdx.x >> 3);
-        tb = first;
-        tile = 0;
-        t_end = first < te ? ((te - first + S - 1) / S) * nf : 0;
-    }
     if (tile >= t_end) return;
-    auto tile_m0 = [&](int t) __attribute__((always_inline)) { return LN ? (tb + (t / nf) * S) * G2_BM : (t / cnt_n) * G2_BM; };
-    auto tile_n0 = [&](int t) __attribute__((always_inline)) { return LN ? (t % nf) * G2_BN : (n_begin + t % cnt_n) * G2_BN; };
-    const int tile_step = LN ? 1 : S;
 
     // ---- LDS-DMA: a reduction tile is 2 x 32 pieces of 1 KiB (8 rows each), 4 + 4 per wave; source offsets (elements)
     unsigned doff[4];
@@ -296,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // lines per instruction — 8-9 us of a 35 us tile go into their issue wherever they are placed; fetching the tile in
     // 16-byte row segments and turning it through the staging area was tried: the register allocator spills all sixteen
     // vectors in front of the stores, and landing them by LDS-DMA has to wait behind the stores round by round).
-    f16x4 rv[RV ? 4 : 1][2][4];
+    f16x4 rv[EPI == EPI_BIAS_RESID ? 4 : 1][2][4];
     auto init_loads = [&](int im0, int in0) __attribute__((always_inline)) {
         int l31 = lane & 31, hi = lane >> 5;
         asm volatile("" : "+v"(l31), "+v"(hi));
@@ -308,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = b[e];
             }
-        if (RV && !(G2_ABLATE & 4)) {
+        if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const half_t *rrow = p.resid + ((size_t)im0 + wq * 64 + j * 32 + l31) * p.N + in0 + wf * 128 + 4 * hi;
@@ -327,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float b = acc[i][0][4 * g + e];
-                    if (RV && !(G2_ABLATE & 4)) {
+                    if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
                         acc[i][1][4 * g + e] = b + (float)rv[i][1][g][e];
                         acc[i][0][4 * g + e] = b + (float)rv[i][0][g][e];
                     } else {
@@ -341,9 +315,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // that every global store is 16 bytes of a full 128-byte row segment.  No barrier: a wave stages and stores its own
     // 64 tokens x 128 features.  `next`: the tile whose initial values are requested between the phases.
     char *const stg = smem + 2 * G2_STAGE + wave * 4096;
-    // LN form: the lane's share of (sum, sum of squares) of its two tokens' rows, over the feature tiles of the token tile so far
-    float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};
-    auto epilogue = [&](int em0, int en0, bool next, int nm0, int nn0, bool ln_first, bool ln_last) __attribute__((always_inline)) {
+    auto epilogue = [&](int em0, int en0, bool next, int nm0, int nn0) __attribute__((always_inline)) {
         // (opaque copies: every address below is computed here, not hoisted out of the tile loop into registers that
         // the accumulators need)
         int l31 = lane & 31, hi = lane >> 5, lane_e = lane;
@@ -362,9 +334,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         // registers that are free hold no 4-register run for the next tile's bias vectors — sixteen of them were spilled.
         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
         u32x16 o16[4];
-        if constexpr (LN) {
-            if (ln_first) { st1[0] = st1[1] = st2[0] = st2[1] = 0.f; }
-        }
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -384,60 +353,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h[e] = (_Float16)a[4 * g + e];
                         }
-                        if constexpr (LN) {                 // statistics over the ROUNDED values: what a LayerNorm kernel would read
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { const float v = (float)h[e]; st1[j] += v; st2[j] = __builtin_fmaf(v, v, st2[j]); }
-                        }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
                         o16[ip * 2 + j][(ii * 4 + g) * 2] = hb.x;
                         o16[ip * 2 + j][(ii * 4 + g) * 2 + 1] = hb.y;
                     }
-        __builtin_amdgcn_sched_barrier(0);
-        float ln_rstd[2] = {0.f, 0.f}, ln_nmr[2] = {0.f, 0.f};
-        if constexpr (LN) {
-            if (ln_last) {
-                // ---- the row statistics are complete in this tile: the other feature half of every tile lives in wave (wq, wf ^ 1)
-                float2 *sc = p.ln_scratch + ((size_t)em0 + wq * 64 + l31) * 2;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    st1[j] += __shfl_xor(st1[j], 32);
-                    st2[j] += __shfl_xor(st2[j], 32);
-                    if (hi == 0) sc[(size_t)j * 64 + wf] = make_float2(st1[j], st2[j]);
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float2 a = sc[(size_t)j * 64], b = sc[(size_t)j * 64 + 1];
-                    layernorm_scale(a.x + b.x, a.y + b.y, 1.0f / (float)p.N, ln_rstd[j], ln_nmr[j]);
-                }
-                // ---- this tile, normalised in registers: y = v (gamma rstd) + (gamma nmr + beta), rounded once (layer_tail's form)
-#pragma unroll
-                for (int ip = 0; ip < 2; ++ip)
-#pragma unroll
-                    for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int feat = en0 + wf * 128 + (2 * ip + ii) * 32 + 8 * g + 4 * hi;
-                            const f32x4 gv = *(const f32x4 *)(p.gamma + feat), bv = *(const f32x4 *)(p.beta + feat);
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) {
-                                const uint2 hb = {o16[ip * 2 + j][(ii * 4 + g) * 2], o16[ip * 2 + j][(ii * 4 + g) * 2 + 1]};
-                                const f16x4 h = __builtin_bit_cast(f16x4, hb);
-                                f32x4 r;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf((float)h[e], gv[e] * ln_rstd[j], __builtin_fmaf(gv[e], ln_nmr[j], bv[e]));
-                                asm("" : "+v"(r));
-                                f16x4 y;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) y[e] = (_Float16)r[e];
-                                const uint2 yb = __builtin_bit_cast(uint2, y);
-                                o16[ip * 2 + j][(ii * 4 + g) * 2] = yb.x;
-                                o16[ip * 2 + j][(ii * 4 + g) * 2 + 1] = yb.y;
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-            }
-        }
         __builtin_amdgcn_sched_barrier(0);
         // the next tile's initial values: every load of the tile boundary is issued here, in front of the first store (vmcnt
         // retires in issue order: a load behind a store would wait for that store's acknowledgement) and BEHIND phase 1 (the
@@ -478,38 +397,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-        if constexpr (LN) {
-            if (ln_last && !(G2_ABLATE & 32)) {
-                // ---- the earlier feature tiles of the row: this wave's 64 tokens x 128 features of each, as 16-byte row segments
-                // (lane = segment lane & 15 of row 4 it + (lane >> 4)); a row's (rstd, nmr) sit in lanes (row & 31) of token block row >> 5
-                const int ch = lane_e & 15, r4 = lane_e >> 4;
-                for (int fp = 0; fp + 1 < nf; ++fp) {
-                    const int feat = fp * G2_BN + wf * 128 + ch * 8;
-                    const f32x4 g0 = *(const f32x4 *)(p.gamma + feat), g1 = *(const f32x4 *)(p.gamma + feat + 4);
-                    const f32x4 b0 = *(const f32x4 *)(p.beta + feat), b1 = *(const f32x4 *)(p.beta + feat + 4);
-                    half_t *base = p.C + ((size_t)em0 + wq * 64 + r4) * p.N + feat;
-#pragma unroll
-                    for (int it0 = 0; it0 < 16; it0 += 4) {
-                        uint4 v[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) v[u] = *(const uint4 *)(base + (size_t)(it0 + u) * 4 * p.N);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int it = it0 + u, src = (it * 4 + r4) & 31;
-                            const float rs = __shfl(ln_rstd[it >> 3], src), nm = __shfl(ln_nmr[it >> 3], src);
-                            const f16x8 h = __builtin_bit_cast(f16x8, v[u]);
-                            f16x8 y;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) {
-                                const float gg = e < 4 ? g0[e & 3] : g1[e & 3], bb = e < 4 ? b0[e & 3] : b1[e & 3];
-                                y[e] = (_Float16)rounded_f32(__builtin_fmaf((float)h[e], gg * rs, __builtin_fmaf(gg, nm, bb)));
-                            }
-                            *(uint4 *)(base + (size_t)it * 4 * p.N) = __builtin_bit_cast(uint4, y);
-                        }
-                    }
-                }
-            }
-        }
     };
 
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
@@ -520,7 +407,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // (a one-time start delay that spreads the workgroups' phases over a tile period was tried: no gain — the cost of an
     // epilogue is its CU's own store issue, 31 B/cycle/CU into L2 and 18 when the whole chip streams to HBM,
     // tools/ubench/store_issue.hip — not the other CUs' bursts)
-    int m0 = tile_m0(tile), n0 = tile_n0(tile);
+    int m0 = (tile / cnt_n) * G2_BM, n0 = (n_begin + tile % cnt_n) * G2_BN;
     {   // the first reduction tile of the first output tile
         const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
         dma_piece(a, smem, I0{}); dma_piece(a, smem, I1{}); dma_piece(a, smem, I2{}); dma_piece(a, smem, I3{});
@@ -568,11 +455,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     };
     int stage = 0;
     for (;;) {
-        const int next = tile + tile_step;
+        const int next = tile + S;
         const bool more = next < t_end;
         // (after the last output tile the stream requests this tile's first reduction tile once more: a request that
         // is never read costs less than a branch around every request)
-        const int nm0 = more ? tile_m0(next) : m0, nn0 = more ? tile_n0(next) : n0;
+        const int nm0 = more ? (next / cnt_n) * G2_BM : m0, nn0 = more ? (n_begin + next % cnt_n) * G2_BN : n0;
         const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
         {   // ---- reduction tile 0: the previous output tile is finished behind its barrier
             tile_barrier(f1);
@@ -588,7 +475,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             if constexpr (Q4) q4_expand_all((unsigned)(nstage - smem));
             if (have_prev) {
                 mfma_step(f1);                         // the last k-step of the previous output tile
-                epilogue(pm0, pn0, true, m0, n0, pn0 == 0, pn0 + G2_BN == p.N);
+                epilogue(pm0, pn0, true, m0, n0);
                 init_acc();
             }
             read_frag(f0, I0{});
@@ -615,22 +502,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // the request issued behind the last output tile must not outlive the workgroup
     tile_barrier(f1);
     mfma_step(f1);
-    epilogue(pm0, pn0, false, 0, 0, pn0 == 0, pn0 + G2_BN == p.N);
+    epilogue(pm0, pn0, false, 0, 0);
 }
 
 bool gemm256_supported(const GemmWeight &W, int M_pad) {
     return (W.type == GW_F16 ? W.w16 != nullptr : W.qs != nullptr && W.sc != nullptr) && W.N % G2_BN == 0 && W.K % G2_BK == 0 && W.K >= 2 * G2_BK && M_pad % G2_BM == 0 && M_pad > 0;
 }
 
-bool gemm256_ln_supported(const GemmWeight &W, int M_pad) {
-    return gemm256_supported(W, M_pad) && W.N <= 4 * G2_BN;     // (a row of at most four tiles: the statistics wait in four registers)
-}
-
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream, const float *ln_gamma, const float *ln_beta, void *ln_scratch) {
+                    int epilogue, hipStream_t stream) {
     Gemm256Args a;
     a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C; a.qs = W.qs; a.sc = W.sc;
-    a.gamma = ln_gamma; a.beta = ln_beta; a.ln_scratch = (float2 *)ln_scratch;
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
     a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
     // feature groups: only where W (N x K f16) overflows an XCD's L2 share and reading the activations twice is the cheaper
@@ -638,7 +520,7 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     // (measured, bert-base / mpnet dimensions: up-projection -2.5 %; FETCH_SIZE per launch in profiles/)
     a.n_groups = 1;
     // (a q4 matrix is 9 / 32 or 10 / 32 of that: the up-projection's 1.3 MiB stay resident beside everything else)
-    if (epilogue != EPI_BIAS_RESID_LN && W.type == GW_F16 && (size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G2_BM >= 64) a.n_groups = 2;
+    if (W.type == GW_F16 && (size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G2_BM >= 64) a.n_groups = 2;
     // one persistent workgroup per CU (256 on an MI355X, a multiple of the 8 XCDs), fewer when there are fewer tiles
     static int n_cu[MAX_HIP_DEVICES] = {};
     int dev = 0;
@@ -650,7 +532,7 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
     const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
-    static DeviceFlags configured[12];
+    static DeviceFlags configured[9];
     auto go = [&](auto kernel, int e) {
         configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
@@ -659,14 +541,13 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
         constexpr int E = decltype(epi_tag)::value;
         switch (W.type) {
             case GW_F16: go(gemm256_kernel<E, GW_F16>, E); break;
-            case GW_Q4_0: go(gemm256_kernel<E, GW_Q4_0>, 4 + E); break;
-            default: go(gemm256_kernel<E, GW_Q4_1>, 8 + E); break;
+            case GW_Q4_0: go(gemm256_kernel<E, GW_Q4_0>, 3 + E); break;
+            default: go(gemm256_kernel<E, GW_Q4_1>, 6 + E); break;
         }
     };
     switch (epilogue) {
         case EPI_BIAS: by_type(std::integral_constant<int, EPI_BIAS>{}); break;
         case EPI_BIAS_GELU: by_type(std::integral_constant<int, EPI_BIAS_GELU>{}); break;
-        case EPI_BIAS_RESID_LN: by_type(std::integral_constant<int, EPI_BIAS_RESID_LN>{}); break;
         default: by_type(std::integral_constant<int, EPI_BIAS_RESID>{}); break;
     }
 }

@@ -53,7 +53,7 @@ constexpr int GEMM_BM = 128;   // token tile
 constexpr int GEMM_BN = 128;   // feature tile
 constexpr int GEMM_BK = 64;    // reduction tile (two 32-weight quant blocks)
 
-enum Epilogue : int { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2, EPI_BIAS_RESID_LN = 3 };   // (the last: gemm256 only)
+enum Epilogue : int { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESID = 2 };
 enum GemmWType : int { GW_F16 = 0, GW_Q4_0 = 1, GW_Q4_1 = 2 };
 
 // A weight matrix W[N][K] (out-features x in-features) in its HBM layout.
@@ -80,10 +80,8 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
                       int M_pad, int epilogue, hipStream_t stream);
 // Large-tile variant (gemm256.hip): 256 x 256 x 64 tiles, 8 waves; f16 weights, N % 256 == 0, M_pad % 256 == 0.
 bool gemm256_supported(const GemmWeight &W, int M_pad);
-bool gemm256_ln_supported(const GemmWeight &W, int M_pad);
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream, const float *ln_gamma = nullptr, const float *ln_beta = nullptr,
-                    void *ln_scratch = nullptr);
+                    int epilogue, hipStream_t stream);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);
