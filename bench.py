@@ -360,6 +360,51 @@ def latency_b1(tmpdir, calls=200):
     return out
 
 
+def encode_batch_rate(tmpdir, n_texts=32768, calls=5):
+    """Strings in, embeddings out: bert_encode_batch (what the reference's ctypes callers use: sample_dylib.py:50-58,
+    run_mteb.py:57-72) on English-like text of ~22 words per line (the length of the reference's sample_client_texts.txt lines)
+    with a WordPiece vocabulary built from the same text; the host tokenizes group g + 1 on `threads` threads while group g is
+    on the GPU.  texts/s, median of `calls` calls; the pointer arrays are built once outside the timed calls."""
+    import collections
+    import ctypes as C
+    import random
+    import re
+
+    rng = random.Random(1)
+    syll = ["ta", "re", "mo", "in", "ul", "es", "ka", "do", "vi", "ne", "or", "shi", "pla", "con", "ter", "ing", "ed", "ly", "un", "pre"]
+    words = ["".join(rng.choice(syll) for _ in range(rng.randint(1, 4))) for _ in range(6000)]
+    lines = [" ".join(rng.choice(words) for _ in range(rng.randint(5, 40))) + rng.choice([".", "?", "!", ""]) for _ in range(3000)]
+    freq = collections.Counter(w for l in lines for w in re.findall(r"[a-z0-9]+", l.lower()))
+    hp = gf.MODEL_DIMS["minilm-l6"]
+    vocab = ["[PAD]"] + [f"[unused{i}]" for i in range(99)] + ["[UNK]", "[CLS]", "[SEP]", "[MASK]"]
+    vocab += [chr(c) for c in range(33, 127)] + ["##" + chr(c) for c in range(97, 123)] + ["##" + str(d) for d in range(10)]
+    vocab += [w for w, _ in freq.most_common(12000)] + ["##" + x for x in ("s", "ed", "ing", "ly", "er", "es", "tion", "al", "ment", "ness")]
+    vocab = list(dict.fromkeys(vocab))
+    vocab += [f"[unused{i}]" for i in range(len(vocab), hp.n_vocab)]
+    path = os.path.join(tmpdir, "minilm_text_vocab.bin")
+    gf.write_model(path, hp, gf.synthetic_weights(hp, 0, "sensitive"), gf.FTYPE_BY_NAME["f16"], vocab=[v.encode("utf-8") for v in vocab[:hp.n_vocab]])
+    m = pybert.BertModel(path)
+    texts = [lines[i % len(lines)].encode("utf-8") for i in range(n_texts)]
+    out = np.empty((n_texts, hp.n_embd), dtype=np.float32)
+    out_ptrs = (C.POINTER(C.c_float) * n_texts)(*[out[i].ctypes.data_as(C.POINTER(C.c_float)) for i in range(n_texts)])
+    txt = (C.c_char_p * n_texts)(*texts)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    n_tok = sum(len(t) for t in m.tokenize_batch(texts[:2000], threads)) / 2000.0
+    ts = []
+    for i in range(calls + 1):
+        t0 = time.perf_counter()
+        m.lib.bert_encode_batch(m.ctx, threads, 16, n_texts, txt, out_ptrs)
+        if i:
+            ts.append(time.perf_counter() - t0)
+    ok = bool(np.isfinite(out).all() and abs(float(np.linalg.norm(out[0])) - 1) < 1e-3)
+    same = bool(np.array_equal(out[0], m.encode(texts[0].decode())))
+    m.close()
+    med = float(np.median(ts))
+    return {"value": n_texts / med, "unit": "texts/s", "ms_per_call": 1e3 * med, "n_texts": n_texts, "mean_tokens_per_text": n_tok,
+            "host_threads": threads, "finite_unit_norm": ok, "row0_equals_bert_encode": same,
+            "entry": "bert_encode_batch (host strings -> tokenizer on host threads, pipelined with the GPU -> host embeddings), all-MiniLM-L6-v2 dims f16"}
+
+
 def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None, sample=None):
     """Oracle (ggml-faithful mode) on the host cores over a bounded sample of the same sentences: by default the step's
     sentences in order until the time budget is spent; `sample`: exactly these sentence indices."""
@@ -556,6 +601,7 @@ def main():
         if rank == 0:
             if world == 1 and args.config == 1 and args.also is None:
                 extras["latency_b1"] = latency_b1(tmpdir)
+                extras["encode_batch_text"] = encode_batch_rate(tmpdir)
             if extras:
                 line["also"] = extras
             # the line is long: a compact table of every entry as the LAST object, where a truncated log still shows it
@@ -571,7 +617,12 @@ def main():
                                           "sample_rows_equal_host_call": e.get("sample_rows_equal_host_call")}.items() if v is not None}
             line["summary"] = {"config1": brief(dict(e, value=res["value"], ms_per_step=res["ms_per_step"]))}
             for k, v in extras.items():
-                line["summary"][k] = brief(v) if k != "latency_b1" else {kk: round(vv["median_us"], 1) for kk, vv in v.items() if isinstance(vv, dict)}
+                if k == "latency_b1":
+                    line["summary"][k] = {kk: round(vv["median_us"], 1) for kk, vv in v.items() if isinstance(vv, dict)}
+                elif k == "encode_batch_text":
+                    line["summary"][k] = {"texts_per_s": round(v["value"], 1), "mean_tokens_per_text": round(v["mean_tokens_per_text"], 1)}
+                else:
+                    line["summary"][k] = brief(v)
             print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
