@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,6 +42,9 @@ struct bert_ctx {
     std::vector<std::unique_ptr<Engine>> engines;
     // host threads of the devices beyond the first, created once at load (multi_device.h)
     std::unique_ptr<ShardWorkers> workers;
+    // host threads of the batch tokenizer (bert_encode_batch / bert_hip_tokenize_batch), created at the first call that asks for
+    // them and kept: a group of 4096 texts tokenizes in about a millisecond, sixteen thread starts cost a third of that
+    mutable std::unique_ptr<ShardWorkers> tok_workers;
     // test knobs (bert_hip_set_option "test_inject_bad_alloc" / "test_rccl_single"): the ABI's catch-all; the exchange step
     // through a 1-rank communicator on a single device
     bool inject_bad_alloc = false, rccl_single = false;
@@ -342,14 +346,12 @@ static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inpu
             for (int32_t i = i0; i < i1; ++i) ctx->tok.tokenize(texts[i], tokens + (size_t)i * N, &n_tokens[i], N);
         }
     };
-    // a thread that cannot be started is not an error: the others (at least the caller) take its share
-    std::vector<std::thread> pool;
-    try {
-        for (int k = 1; k < nt; ++k) pool.emplace_back(work);
-    } catch (const std::system_error &) {
-    }
-    work();
-    for (auto &th : pool) th.join();
+    // persistent workers (a thread that could not be started is not an error: the others, at least the caller, take its share)
+    if (!ctx->tok_workers || ctx->tok_workers->n_threads() < nt - 1) ctx->tok_workers.reset(new ShardWorkers(nt - 1));
+    std::vector<int> each((size_t)nt + 1);
+    for (int k = 0; k <= nt; ++k) each[k] = k;                   // "shard" k = worker k's turn at the shared counter
+    std::string err;
+    if (ctx->tok_workers->run(each, [&](int, int, int) { work(); return 0; }, &err) != 0) throw std::runtime_error("tokenizer worker: " + err);
 }
 
 // number of inputs encoded (stops at the first failure, later outputs untouched)
