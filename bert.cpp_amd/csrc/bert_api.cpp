@@ -306,8 +306,20 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
     std::vector<int32_t> packed((size_t)cu[B]);
     for (int32_t b = 0; b < B; ++b) memcpy(packed.data() + cu[b], batch_tokens[b], sizeof(int32_t) * n_tokens[b]);
     const int H = ctx->hp.n_embd;
-    std::vector<float> out((size_t)B * H);
     std::string err;
+    // the caller's rows are usually the rows of ONE matrix (NumPy rows through ctypes: reference examples/sample_dylib.py:50-51):
+    // then the engine writes them in place; scattered rows go through a matrix of our own.  (A device error half way through a
+    // call of several chunks leaves the rows of the finished chunks written in the first case, nothing in the second.)
+    bool rows_of_one_matrix = true;
+    for (int32_t b = 1; b < B && rows_of_one_matrix; ++b) rows_of_one_matrix = batch_embeddings[b] == batch_embeddings[0] + (size_t)b * H;
+    if (rows_of_one_matrix) {
+        if (eval_packed_all_devices(ctx, packed.data(), cu.data(), B, batch_embeddings[0], err) != 0) {
+            fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
+            return -1;
+        }
+        return B;
+    }
+    std::vector<float> out((size_t)B * H);
     if (eval_packed_all_devices(ctx, packed.data(), cu.data(), B, out.data(), err) != 0) {
         fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
         return -1;

@@ -264,16 +264,20 @@ class BertModel:
         self.lib.bert_eval(self.ctx, n_threads, _i32p(toks), len(toks), _f32p(out))
         return out
 
-    def eval_batch(self, sentences: Sequence[Sequence[int]], n_threads: int = 6) -> np.ndarray:
-        """bert_eval_batch through per-sentence host pointers, exactly like a C caller."""
+    def eval_batch(self, sentences: Sequence[Sequence[int]], n_threads: int = 6, scattered: bool = False) -> np.ndarray:
+        """bert_eval_batch through per-sentence host pointers, exactly like a C caller.  scattered: the result rows are
+        every other row of a wider matrix (rows that are NOT the rows of one [B][n_embd] matrix)."""
         B = len(sentences)
         arrs = [np.ascontiguousarray(s, dtype=np.int32) for s in sentences]
-        out = np.full((B, self.n_embd), np.nan, dtype=np.float32)
+        wide = np.full((B, 2 * self.n_embd + 3 if scattered else self.n_embd), np.nan, dtype=np.float32)
+        out = wide[:, : self.n_embd]
         tok_ptrs = (C.POINTER(C.c_int32) * B)(*[_i32p(a) for a in arrs])
         lens = np.array([len(a) for a in arrs], dtype=np.int32)
-        out_ptrs = (C.POINTER(C.c_float) * B)(*[_f32p(out[i]) for i in range(B)])
+        out_ptrs = (C.POINTER(C.c_float) * B)(*[C.cast(wide[i].ctypes.data, C.POINTER(C.c_float)) for i in range(B)])
         self.lib.bert_eval_batch(self.ctx, n_threads, B, tok_ptrs, _i32p(lens), out_ptrs)
-        return out
+        if scattered:
+            assert np.isnan(wide[:, self.n_embd:]).all()          # nothing written beside the rows
+        return np.ascontiguousarray(out)
 
     def encode(self, text: str, n_threads: int = 6) -> np.ndarray:
         out = np.full(self.n_embd, np.nan, dtype=np.float32)

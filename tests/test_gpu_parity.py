@@ -523,6 +523,24 @@ def test_api_equivalences_and_batch_independence(make_model, dims, ftype):
     assert np.array_equal(m.eval_batch(sents), batch)
 
 
+def test_eval_batch_rows_in_place_or_scattered(make_model, capfd):
+    """bert_eval_batch's result pointers (bert.h: `float **batch_embeddings`): rows of one matrix are written in place by the
+    engine, scattered rows go through a matrix of the library's own — the same embeddings; and a sentence that cannot be
+    evaluated leaves its row and the rows behind it untouched either way (reference bert.cpp:765-769)."""
+    path, hp = make_model("tiny-h128", "f16", 1)
+    m = pybert.BertModel(path)
+    rng = np.random.default_rng(9)
+    sents = [rng.integers(0, hp.n_vocab, size=int(n)).astype(np.int32) for n in rng.integers(1, hp.n_max_tokens + 1, size=70)]
+    a = m.eval_batch(sents)
+    b = m.eval_batch(sents, scattered=True)
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    bad = sents[:5] + [np.zeros(hp.n_max_tokens + 1, dtype=np.int32)] + sents[5:9]
+    for scattered in (False, True):
+        out = m.eval_batch(bad, scattered=scattered)
+        assert np.array_equal(out[:5], a[:5]) and np.isnan(out[5:]).all()
+    capfd.readouterr()
+
+
 def test_host_path_pipelines_chunks(make_model):
     """eval_packed_host keeps two chunks in flight (stage / compute / unpack overlap, engine.hip): many chunks of
     uneven size, buffers growing between calls, a single-chunk call in between — always the bits of the unchunked call."""
