@@ -80,8 +80,11 @@ with open(os.path.join(P, f"{tag}_gemm_calibration.txt"), "w") as f:
             f"# beside it on the same box: profiles/{tag}_kernel_stats.txt, config 3: gemm256_kernel<0> QKV + bias, <1> FFN up + bias + GELU, <2> attention-out / FFN down + bias + residual (average of the two)\n" +
             "\n".join(cal) + "\n")
 print("profiles/ refreshed at", commit, {k: round(v[2], 3) for k, v in busy.items()})
-for k, v in [("config1", bench)] + [kv for kv in bench["also"].items() if "value" in kv[1]]:
+for k, v in [("config1", bench)] + [kv for kv in bench["also"].items() if "value" in kv[1] and "ms_per_step" in kv[1]]:
     print(f"{k:22s} {v['value']:12.0f} /s  {v['ms_per_step']:8.3f} ms  frac {v.get('path_mfma_frac', 0):.3f}  host {(v.get('host_api') or {}).get('value', 0):10.0f}  cpu {(v.get('cpu_baseline') or {}).get('value', 0):8.2f}  x{v.get('speedup_vs_cpu', 0):.0f}  cos {v.get('mean_cosine_vs_cpu')}")
+enc = bench["also"].get("encode_batch_text")
+if enc:
+    print(f"encode_batch_text      {enc['value']:12.0f} texts/s  {enc['ms_per_call']:8.3f} ms per call of {enc['n_texts']} texts, {enc['mean_tokens_per_text']:.1f} tokens per text, {enc['host_threads']} host threads")
 lat = bench["also"].get("latency_b1", {})
 for k, v in lat.items():
     if isinstance(v, dict):
