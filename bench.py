@@ -435,6 +435,36 @@ def cpu_baseline_and_cosine(res, budget_s=12.0, max_sent=4096, gpu=None, sample=
     return base, float(np.mean(coss)), float(np.min(coss)), n
 
 
+def cpu_torch_fp32(hp, seq_len, budget_s=6.0):
+    """The second, independent CPU number of SURVEY.md §8(d): a HuggingFace `BertModel` of the same dimensions in fp32 on torch's
+    CPU backend (oneDNN GEMMs, all usable cores), batches of 16 sentences of `seq_len` tokens — a tuned CPU library's rate beside the
+    restated ggml-semantics path's.  None when transformers is not importable."""
+    try:
+        import torch
+        import transformers
+    except ImportError:
+        return None
+    from oracle import oracle as orc
+    cores = int(min(orc.usable_cores(), 64))
+    torch.set_num_threads(cores)
+    cfg = transformers.BertConfig(vocab_size=hp.n_vocab, hidden_size=hp.n_embd, num_hidden_layers=hp.n_layer, num_attention_heads=hp.n_head,
+                                  intermediate_size=hp.n_intermediate, max_position_embeddings=hp.n_max_tokens, hidden_act="gelu_new",
+                                  layer_norm_eps=1e-5)
+    model = transformers.BertModel(cfg, add_pooling_layer=False).eval()
+    ids = torch.from_numpy(gf.synthetic_token_ids(16, seq_len, hp.n_vocab, seed=3).astype(np.int64))
+    with torch.no_grad():
+        model(input_ids=ids)                                   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or n == 0:
+            h = model(input_ids=ids).last_hidden_state
+            e = h.mean(dim=1)
+            e = e / e.norm(dim=1, keepdim=True)
+            n += ids.shape[0]
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "sentences/s", "cores": cores, "kind": "independent",
+            "sample": f"{n} sentences of {seq_len} tokens in batches of 16 through transformers.BertModel (fp32, torch CPU, {cores} threads), {dt:.1f} s"}
+
+
 SHARE_ROWS = {}       # config4_share: the sampled rows of the host-to-host call, compared with the gather entry point's
 
 
@@ -562,6 +592,8 @@ def main():
             cfg = res["cfg"]
             prof_steps = int(min(20, max(2, 0.4 / (res["ms_per_step"] * 1e-3))))        # (about 0.4 s of profiled steps)
             e = report(res, world, torch, device, args, prof_steps=prof_steps, cpu_budget=12.0, replay_groups=3)
+            if world == 1 and not args.no_cpu_baseline and cfg["seq_len"]:
+                e["cpu_torch_fp32"] = cpu_torch_fp32(res["hp"], cfg["seq_len"])
             line = {
                 "metric": "sentences/sec (seq_len=%s)" % cfg["seq_len"], "value": res["value"], "unit": "sentences/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
