@@ -593,7 +593,10 @@ def main():
             prof_steps = int(min(20, max(2, 0.4 / (res["ms_per_step"] * 1e-3))))        # (about 0.4 s of profiled steps)
             e = report(res, world, torch, device, args, prof_steps=prof_steps, cpu_budget=12.0, replay_groups=3)
             if world == 1 and not args.no_cpu_baseline and cfg["seq_len"]:
-                e["cpu_torch_fp32"] = cpu_torch_fp32(res["hp"], cfg["seq_len"])
+                try:
+                    e["cpu_torch_fp32"] = cpu_torch_fp32(res["hp"], cfg["seq_len"])
+                except Exception as ex:
+                    e["cpu_torch_fp32"] = {"error": f"{type(ex).__name__}: {ex}"}
             line = {
                 "metric": "sentences/sec (seq_len=%s)" % cfg["seq_len"], "value": res["value"], "unit": "sentences/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
@@ -622,18 +625,28 @@ def main():
         for cid in also:
             big = CONFIGS[cid]["dims"] in ("bert-base", "mpnet-dims")
             share = bool(CONFIGS[cid].get("share"))                   # (a step is one 125,000-sentence call: about three seconds)
-            r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir, steps=1 if share else 3 if big else max(10, args.steps // 4),
-                            warmup=1 if big else 5, repeat=2 if share else 3)
-            if rank == 0:
-                extras[r2["cfg"].get("key", f"config{cid}")] = report(r2, world, torch, device, args, prof_steps=2 if big else 3,
-                                                                       cpu_budget=8.0 if big else 4.0)
-            else:
-                kernel_roofline(r2, torch, device, steps=2 if big else 3)
-            r2["model"].close()
+            key = CONFIGS[cid].get("key", f"config{cid}")
+            try:
+                r2 = run_config(cid, args, rank, world, device, dist, torch, tmpdir, steps=1 if share else 3 if big else max(10, args.steps // 4),
+                                warmup=1 if big else 5, repeat=2 if share else 3)
+                if rank == 0:
+                    extras[key] = report(r2, world, torch, device, args, prof_steps=2 if big else 3, cpu_budget=8.0 if big else 4.0)
+                else:
+                    kernel_roofline(r2, torch, device, steps=2 if big else 3)
+                r2["model"].close()
+            except (Exception, SystemExit) as ex:                      # an auxiliary entry must never cost the headline line (its error is in the line and on stderr)
+                if world > 1:
+                    raise
+                extras[key] = {"workload": CONFIGS[cid]["name"], "error": f"{type(ex).__name__}: {ex}"}
+                print(f"bench.py: entry {key} failed: {ex}", file=sys.stderr)
         if rank == 0:
             if world == 1 and args.config == 1 and args.also is None:
-                extras["latency_b1"] = latency_b1(tmpdir)
-                extras["encode_batch_text"] = encode_batch_rate(tmpdir)
+                for k, fn in (("latency_b1", latency_b1), ("encode_batch_text", encode_batch_rate)):
+                    try:
+                        extras[k] = fn(tmpdir)
+                    except Exception as ex:
+                        extras[k] = {"error": f"{type(ex).__name__}: {ex}"}
+                        print(f"bench.py: entry {k} failed: {ex}", file=sys.stderr)
             if extras:
                 line["also"] = extras
             # the line is long: a compact table of every entry as the LAST object, where a truncated log still shows it
@@ -649,7 +662,9 @@ def main():
                                           "sample_rows_equal_host_call": e.get("sample_rows_equal_host_call")}.items() if v is not None}
             line["summary"] = {"config1": brief(dict(e, value=res["value"], ms_per_step=res["ms_per_step"]))}
             for k, v in extras.items():
-                if k == "latency_b1":
+                if "error" in v:
+                    line["summary"][k] = {"error": v["error"]}
+                elif k == "latency_b1":
                     line["summary"][k] = {kk: round(vv["median_us"], 1) for kk, vv in v.items() if isinstance(vv, dict)}
                 elif k == "encode_batch_text":
                     line["summary"][k] = {"texts_per_s": round(v["value"], 1), "mean_tokens_per_text": round(v["mean_tokens_per_text"], 1)}
