@@ -70,6 +70,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
             __builtin_amdgcn_global_load_lds(AS_GLOBAL(wbase + (size_t)row * K * 2 + src * 16), AS_LDS(smem + pc * 1024), 16, 0, 0);
         }
     }
+    // ---- LN != 0: the 32 pre-LayerNorm rows -> LDS behind the weights, run (n, g) of all lanes = one 1 KiB piece (lane
+    // (l31, hi): features 32 n + 8 g + 4 hi .. + 3 of its token).  In registers the row's 64 x H floats leave the compiler
+    // no room to keep the parameter reads in flight (it waited for every pair in turn: 4 us per launch).
+    char *const xl = smem + (size_t)32 * K * 2;
+    if constexpr (LN != 0) {
+        const char *vrow = (const char *)(p.V + (size_t)tok * K + 4 * hi);
+        for (int pc = wave; pc < 16 * NT; pc += n_waves)
+            __builtin_amdgcn_global_load_lds(AS_GLOBAL(vrow + (pc >> 2) * 128 + (pc & 3) * 32), AS_LDS(xl + pc * 1024), 16, 0, 0);
+    }
 
     if (wave != 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -110,7 +119,13 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
     if constexpr (LN != 0) {
         // ---- LayerNorm in registers, then k ascending over the whole row (K = H = 128 NT)
         f16x4 y[4 * NT][4];
-        layernorm_runs<LN == 1, NT>(p.V + (size_t)tok * K, p.gamma, p.beta, hi, y);
+        layernorm_runs_of<LN == 1, NT>(
+            [&](int n, int g) __attribute__((always_inline)) { return *(const f32x4 *)(xl + (n * 4 + g) * 1024 + lane * 16); },
+            [&]() __attribute__((always_inline)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block and the rows have landed
+                __builtin_amdgcn_s_barrier();
+            },
+            p.gamma, p.beta, hi, y);
         if (blockIdx.x == 0) {
             half_t *orow = p.ln_out + (size_t)tok * K;
 #pragma unroll
@@ -118,8 +133,6 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) *(f16x4 *)(orow + 32 * n + 8 * g + 4 * hi) = y[n][g];
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block has landed
-        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int q = 0; q < 8 * NT; ++q) {
             constexpr int dummy = 0; (void)dummy;
@@ -228,7 +241,7 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
     a.A = A; a.V = V; a.gamma = gamma; a.beta = beta; a.ln_out = ln_out;
     a.bias = bias; a.resid = resid; a.out16 = out16; a.out32 = out32; a.N = W.N; a.K = W.K;
     const dim3 grid(W.N / 32, n_token_blocks), block(W.K >= 1024 ? 256 : 128);     // wave 0 computes, the others help to request the weights
-    const size_t lds = (size_t)32 * W.K * 2;                 // the tile's weight rows
+    const size_t lds = (size_t)32 * W.K * 2 + (V ? (size_t)32 * W.K * 4 : 0);     // the tile's weight rows (+ the pre-LayerNorm rows)
     static DeviceFlags configured[8];
     auto go = [&](auto kernel, int m) {
         if (lds > 64 * 1024) configure_once(configured[m], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });

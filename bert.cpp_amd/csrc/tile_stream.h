@@ -196,20 +196,31 @@ __device__ __forceinline__ uint4 q4_expand_chunk(const RawBlock &r, int c) {
 // PAIR (LayerNorm 1): the statistics are the sum of two half-row sums (features with (f & 127) < 64: layer_tail's U wave;
 // the rest: its D wave), each summed block by block, register by register, then across the lane halves; !PAIR (LayerNorm
 // 2): one sum over all blocks (the D wave owns whole rows).  Result: the normalised runs, f16.
-template <bool PAIR, int NT>
-__device__ __forceinline__ void layernorm_runs(const float *row, const float *gamma, const float *beta, int hi, f16x4 (&y)[4 * NT][4]) {
+template <bool PAIR, int NT, class Run, class Landed>
+__device__ __forceinline__ void layernorm_runs_of(Run x, Landed landed, const float *gamma, const float *beta, int hi, f16x4 (&y)[4 * NT][4]) {
     constexpr int H = 128 * NT;
-    f32x4 x[4 * NT][4];
+    // the parameter reads run AHEAD blocks (eight 16-byte loads each) in front of their use — spelled out: the compiler's own
+    // order waits for every pair of loads in turn (48 L2 round trips)
+    constexpr int AHEAD = 2;
+    f32x4 gv[AHEAD + 1][4], bv[AHEAD + 1][4];
+    auto request = [&](int n) __attribute__((always_inline)) {
 #pragma unroll
-    for (int n = 0; n < 4 * NT; ++n)
+        for (int g = 0; g < 4; ++g) {
+            gv[n % (AHEAD + 1)][g] = *(const f32x4 *)(gamma + 32 * n + 8 * g + 4 * hi);
+            bv[n % (AHEAD + 1)][g] = *(const f32x4 *)(beta + 32 * n + 8 * g + 4 * hi);
+        }
+    };
 #pragma unroll
-        for (int g = 0; g < 4; ++g) x[n][g] = *(const f32x4 *)(row + 32 * n + 8 * g + 4 * hi);
+    for (int n = 0; n < AHEAD; ++n) request(n);
+    landed();                          // (runs that arrive by LDS-DMA: the wait for them, behind the first parameter requests)
     float s1 = 0.f, s2 = 0.f;
     auto add_block = [&](float &a1, float &a2, int n) __attribute__((always_inline)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = x(n, g);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { a1 += x[n][g][e]; a2 = __builtin_fmaf(x[n][g][e], x[n][g][e], a2); }
+            for (int e = 0; e < 4; ++e) { a1 += v[e]; a2 = __builtin_fmaf(v[e], v[e], a2); }
+        }
     };
     if constexpr (PAIR) {
         float t1[2] = {0.f, 0.f}, t2[2] = {0.f, 0.f};
@@ -227,21 +238,36 @@ __device__ __forceinline__ void layernorm_runs(const float *row, const float *ga
     }
     float rstd, nmr;
     layernorm_scale(s1, s2, 1.0f / H, rstd, nmr);
+    asm volatile("" ::: "memory");     // (runs that come from LDS are read again instead of being kept: registers for the loads in flight)
 #pragma unroll
-    for (int n = 0; n < 4 * NT; ++n)
+    for (int n = 0; n < 4 * NT; ++n) {
+        if (n + AHEAD < 4 * NT) request(n + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int f = 32 * n + 8 * g + 4 * hi;
-            const f32x4 gv = *(const f32x4 *)(gamma + f), bv = *(const f32x4 *)(beta + f);
+            const f32x4 v = x(n, g), gq = gv[n % (AHEAD + 1)][g], bq = bv[n % (AHEAD + 1)][g];
             // (f32 results, THEN f16: fused into v_fma_mixlo_f16 — one rounding — the compiler's choice depends on the kernel around
             // it.  One opaque hand-over per run of four, so that the f32 math itself still packs into v_pk_fma_f32.)
             f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(x[n][g][e], gv[e] * rstd, __builtin_fmaf(gv[e], nmr, bv[e]));
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(v[e], gq[e] * rstd, __builtin_fmaf(gq[e], nmr, bq[e]));
             asm("" : "+v"(r));
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[n][g][e] = (_Float16)r[e];
         }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the runs from memory: all of the row in registers first
+template <bool PAIR, int NT>
+__device__ __forceinline__ void layernorm_runs(const float *row, const float *gamma, const float *beta, int hi, f16x4 (&y)[4 * NT][4]) {
+    f32x4 x[4 * NT][4];
+#pragma unroll
+    for (int n = 0; n < 4 * NT; ++n)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) x[n][g] = *(const f32x4 *)(row + 32 * n + 8 * g + 4 * hi);
+    layernorm_runs_of<PAIR, NT>([&](int n, int g) __attribute__((always_inline)) { return x[n][g]; }, [] {}, gamma, beta, hi, y);
 }
 
 }  // namespace bert_hip
