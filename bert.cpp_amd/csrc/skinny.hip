@@ -54,7 +54,8 @@ template <int MODE, int LN, int NT>
 __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // wave 0 owns the tile; waves 1 .. only help to request the weight block (one wave issues a 96 KiB block in 2.8 us,
-    // four in 0.7) and leave at the barrier
+    // four in 0.7) and leave at the barrier.  (The down-projection's k range handed from wave to wave through LDS, every
+    // wave with its quarter of the token fragments requested at once, keeps the bits and costs 1.2 us per launch more.)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int n0 = blockIdx.x * 32, K = p.K, N = p.N, tok = blockIdx.y * 32 + l31;
@@ -85,30 +86,39 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
         __builtin_amdgcn_s_barrier();
         return;
     }
-    // ---- the accumulators' initial value: register r = feature n0 + 8 (r >> 2) + 4 hi + (r & 3) of token `tok`
-    f32x16 acc;
+    // ---- requested now, used behind the wait for the weight block (a load behind the MFMAs, or a wait for these values in
+    // front of the fragment requests, is a round trip of its own): bias and residual of the tile
+    f32x4 bias4[4];
+    [[maybe_unused]] f16x4 resid4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int f = n0 + 8 * g + 4 * hi;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (MODE == SK_PROJ) {                      // x + bo (layer_tail.hip: accp)
-            const f16x4 xv = *(const f16x4 *)(p.resid + (size_t)tok * N + f);
-            const f32x4 bv = *(const f32x4 *)(p.bias + f);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (float)xv[e] + bv[e];
-        } else if constexpr (MODE == SK_UP) {                 // b1 (layer_tail.hip: accU)
-            v = *(const f32x4 *)(p.bias + f);
-        } else if constexpr (MODE == SK_DOWN) {               // b2, + y for the features layer_tail's D wave owns (acc2)
-            v = *(const f32x4 *)(p.bias + f);
-            if ((f & 127) >= 64) {
-                const f16x4 yv = *(const f16x4 *)(p.resid + (size_t)tok * N + f);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (float)yv[e] + v[e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * g + e] = v[e];
+        bias4[g] = *(const f32x4 *)(p.bias + f);
+        if constexpr (MODE == SK_PROJ || MODE == SK_DOWN) resid4[g] = *(const f16x4 *)(p.resid + (size_t)tok * N + f);
     }
+    // the accumulators' initial value: register r = feature n0 + 8 (r >> 2) + 4 hi + (r & 3) of token `tok`
+    f32x16 acc;
+    auto form_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = n0 + 8 * g + 4 * hi;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == SK_PROJ) {                  // x + bo (layer_tail.hip: accp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)resid4[g][e] + bias4[g][e];
+            } else if constexpr (MODE == SK_UP) {             // b1 (layer_tail.hip: accU)
+                v = bias4[g];
+            } else if constexpr (MODE == SK_DOWN) {           // b2, + y for the features layer_tail's D wave owns (acc2)
+                v = bias4[g];
+                if ((f & 127) >= 64) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)resid4[g][e] + v[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g + e] = v[e];
+        }
+    };
 
     const char *wl = smem + (size_t)l31 * cpr * 16;           // this lane's weight row in LDS
     auto weight_frag = [&](int q) __attribute__((always_inline)) {
@@ -126,6 +136,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
                 __builtin_amdgcn_s_barrier();
             },
             p.gamma, p.beta, hi, y);
+        form_acc();
         if (blockIdx.x == 0) {
             half_t *orow = p.ln_out + (size_t)tok * K;
 #pragma unroll
@@ -165,6 +176,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
         static_for<4>([&](auto j_tag) __attribute__((always_inline)) { if (decltype(j_tag)::value < nb) load_b(j_tag, decltype(j_tag)::value); });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block has landed (and the first fragments)
         __builtin_amdgcn_s_barrier();
+        form_acc();
         for (int i0 = 0; i0 < nb; i0 += 4) {
             static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_tag)::value;
@@ -183,10 +195,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
     for (int g = 0; g < 4; ++g) {
         const int f = n0 + 8 * g + 4 * hi;
         if constexpr (MODE == SK_QKV) {                       // acc + bias, one rounding (gemm.hip / qkv_attention2.hip)
-            const f32x4 bv = *(const f32x4 *)(p.bias + f);
             f16x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (_Float16)(acc[4 * g + e] + bv[e]);
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)(acc[4 * g + e] + bias4[g][e]);
             *(f16x4 *)(p.out16 + (size_t)tok * N + f) = o;
         } else if constexpr (MODE == SK_UP) {                 // packed-f16 GELU of adjacent pairs (layer_tail.hip: gelu_pair)
             const f16x2_t g0 = gelu_pk16(acc[4 * g], acc[4 * g + 1]), g1 = gelu_pk16(acc[4 * g + 2], acc[4 * g + 3]);
@@ -201,9 +212,8 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
             if constexpr (MODE == SK_DOWN) {                  // U's features: the residual comes last (layer_tail.hip, LayerNorm 2)
                 if ((f & 127) < 64) {
-                    const f16x4 yv = *(const f16x4 *)(p.resid + (size_t)tok * N + f);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)yv[e];
+                    for (int e = 0; e < 4; ++e) v[e] += (float)resid4[g][e];
                 }
             }
             *(f32x4 *)(p.out32 + (size_t)tok * N + f) = v;
