@@ -114,16 +114,6 @@ private:
 
     // options
     bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
-    // the latency route in one launch (sentence_kernel.hip): 2 = one launch (falls back to 1 if the team of one XCD does not
-    // form or a barrier gives up), 1 = a launch per mat-mul (skinny.hip)
-    int latency_mode_ = 2;
-    DevBuf team_;                              // 32 barrier epochs | the rank counter (zeroed once; epochs and ranks grow from launch to launch)
-    unsigned team_epoch_ = 0, team_rank_ = 0;
-    int team_xcd_ = 0;
-    DevBuf sk1_timeline_;                      // tuning (BERT_HIP_SK1_TIMELINE=1)
-    int sk1_timeline_calls_ = 0;
-    int *team_flag_host_ = nullptr, *team_flag_dev_ = nullptr;   // a mapped host word the kernel writes when it gives up
-    bool team_failed();                        // reads and clears the word; true: the route is switched to 1, the team state reset
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
 

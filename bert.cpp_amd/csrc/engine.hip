@@ -215,8 +215,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
         else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false, e->one_launch_ = 0;
     }
-    if (const char *f = getenv("BERT_HIP_LATENCY")) { e->latency_ = strcmp(f, "0") != 0; e->latency_mode_ = strcmp(f, "1") == 0 ? 1 : 2; }
-    if (prop.multiProcessorCount != 256) e->latency_mode_ = 1;               // (eight XCDs of 32 CUs: what the one-launch form counts on)
+    if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
@@ -263,51 +262,10 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
     if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
     if (!ok) { delete e; return nullptr; }
-    // The one-launch latency route: a team of the 32 workgroups of one XCD (contexts of a process take XCDs in turn: two teams
-    // on one XCD would wait for each other's CUs).  Probed here once: does the team form, does a barrier pass.
-    if (e->latency_mode_ == 2 && e->latency_ && !e->layers_.empty() &&
-        sentence_kernel_supported(e->layers_[0]->qkv.w, e->layers_[0]->o.w, e->layers_[0]->ffi.w, e->layers_[0]->ffo.w, mf.hp.n_layer, mf.hp.n_head,
-                                  mf.hp.n_embd / mf.hp.n_head)) {
-        static std::atomic<int> next_xcd{0};
-        e->team_xcd_ = next_xcd.fetch_add(1) & 7;
-        std::string ignored;
-        bool up = e->team_.alloc(256, ignored) && hipHostMalloc((void **)&e->team_flag_host_, 64, hipHostMallocMapped) == hipSuccess;
-        if (up) {
-            *e->team_flag_host_ = 0;
-            up = hipHostGetDevicePointer((void **)&e->team_flag_dev_, e->team_flag_host_, 0) == hipSuccess;
-        }
-        if (up) {
-            launch_sentence_kernel(nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, mf.hp.n_head, e->team_.as<unsigned>(),
-                                   e->team_.as<unsigned>() + 32, e->team_epoch_, e->team_rank_, e->team_xcd_, e->status_.as<int>(), e->team_flag_dev_,
-                                   e->stream_, mf.hp.n_embd);
-            e->team_epoch_ += sentence_kernel_barriers(0);
-            e->team_rank_ += 32;
-            up = hipStreamSynchronize(e->stream_) == hipSuccess && !e->team_failed();
-        }
-        if (!up) {
-            e->latency_mode_ = 1;
-            if (!getenv("BERT_HIP_QUIET")) fprintf(stderr, "bert_hip: the one-launch latency route is not available on this device; using a launch per mat-mul\n");
-        }
-    } else if (e->latency_mode_ == 2) {
-        e->latency_mode_ = 1;
-    }
-    if (getenv("BERT_HIP_SK1_TIMELINE")) { std::string ignored; (void)e->sk1_timeline_.alloc(32 * 128 * 8, ignored); }
     return e;
 }
 
-bool Engine::team_failed() {
-    if (!team_flag_host_ || !*(volatile int *)team_flag_host_) return false;
-    *(volatile int *)team_flag_host_ = 0;
-    latency_mode_ = 1;
-    (void)hipStreamSynchronize(stream_);
-    (void)hipMemset(team_.p, 0, team_.bytes);
-    (void)hipMemset(status_.p, 0, sizeof(int));
-    team_epoch_ = team_rank_ = 0;
-    return true;
-}
-
 Engine::~Engine() {
-    if (team_flag_host_) (void)hipHostFree(team_flag_host_);
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (auto *L : layers_) delete L;
@@ -351,11 +309,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
-    else if (key == "latency") {               // "0": off; "1": a launch per mat-mul; "2": one launch, where the load-time probe passed
-        latency_ = value != "0";
-        if (value == "1") latency_mode_ = 1;
-        else if (value == "2" && team_flag_host_) latency_mode_ = 2;
-    }
+    else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
     else if (key == "profile_replay") {
@@ -531,33 +485,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const bool skinny = latency_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && T <= 128 && max_len <= 128 && (dh == 32 || dh == 64) &&
                         skinny_layer_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w) &&
                         qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
-    // in ONE launch on the 32 CUs of one XCD (sentence_kernel.hip; the same bits); hidden-state taps need the launches
-    const bool one_xcd = skinny && latency_mode_ == 2 && !d_hidden && hp_.n_layer <= 16;
-    if (one_xcd) {
-        ModelLayerWeights mw[16];
-        for (int il = 0; il < hp_.n_layer; ++il) {
-            LayerWeights &L = *layers_[il];
-            mw[il] = {&L.qkv.w, &L.o.w, &L.ffi.w, &L.ffo.w, L.qkv_b.as<float>(), L.o_b.as<float>(), L.ln_att_w.as<float>(), L.ln_att_b.as<float>(),
-                      L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(), L.ln_out_b.as<float>()};
-        }
-        timed("sentence_kernel", hp_.n_layer * (2.0 * Td * 3 * H * H + att_flops + 2.0 * Td * H * H + 4.0 * Td * H * I), s, [&] {
-            launch_sentence_kernel(mw, hp_.n_layer, x, qkv, ctx, y, ff, v32_.as<float>(), d_cu, B, T, nh, team_.as<unsigned>(), team_.as<unsigned>() + 32,
-                                   team_epoch_, team_rank_, team_xcd_, status_.as<int>(), team_flag_dev_, s, H, sk1_timeline_.as<unsigned long long>());
-        });
-        if (sk1_timeline_.p && ++sk1_timeline_calls_ == 20) {           // (tuning: BERT_HIP_SK1_TIMELINE=1 prints the 20th call's phases)
-            (void)hipStreamSynchronize(s);
-            std::vector<unsigned long long> tl(32 * 128);
-            (void)hipMemcpy(tl.data(), sk1_timeline_.p, tl.size() * 8, hipMemcpyDeviceToHost);
-            for (int r : {0, 3, 13, 31}) {
-                fprintf(stderr, "sk1 rank %2d (us since its start; pairs = [phase end, barrier end]):", r);
-                for (int i = 1; i < 128 && tl[r * 128 + i]; ++i) fprintf(stderr, " %.2f", (double)(tl[r * 128 + i] - tl[r * 128]) / 100.0);
-                fprintf(stderr, "\n");
-            }
-        }
-        team_epoch_ += sentence_kernel_barriers(hp_.n_layer);
-        team_rank_ += 32;
-    }
-    if (skinny && !one_xcd) {
+    if (skinny) {
         const int tb = (T + 31) / 32, Lz = hp_.n_layer;
         float *v32 = v32_.as<float>();
         for (int il = 0; il < Lz; ++il) {
@@ -724,9 +652,6 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         if (i >= 1 && !unpack(i - 1)) return fail();           // while chunk i computes; frees the slot chunk i+1 stages into
     }
     if (!unpack(chunks.size() - 1)) return fail();
-    // (the one-launch latency route gave up at a barrier — CUs of its XCD held by somebody else for a second: the call again,
-    // with a launch per mat-mul from now on)
-    if (team_failed()) return eval_packed_host(tokens, cu, B, embeddings, err, d_embeddings);
     return 0;
 }
 

@@ -115,17 +115,6 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
 // the last layer's LayerNorm 2: f32 rows -> f16 rows
 void launch_skinny_layernorm(const float *v, const float *gamma, const float *beta, half_t *out, int n_token_blocks, int H,
                              hipStream_t stream);
-// The latency route in ONE launch (sentence_kernel.hip): all layers on the 32 CUs of one XCD, team barriers between the phases;
-// the same bits as the launches above.  flags: 32 words, ranks: 1 word (zeroed once); epoch0 / rank0: what the launches before
-// this one have used up (sentence_kernel_barriers(n_layer) epochs and 32 ranks each).  status: bit 2 / 3 = the team did not
-// form / a barrier gave up (the results are not valid: the caller falls back to the launches above); host_flag: a mapped host
-// word that gets the same bits (or null).  xcd: the XCD whose 32 CUs form the team.  n_layer = 0: the probe (one barrier).
-bool sentence_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2, int n_layer, int n_head,
-                               int d_head);
-int sentence_kernel_barriers(int n_layer);
-void launch_sentence_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *qkv, half_t *ctx, half_t *y, half_t *ff, float *v32,
-                            const int32_t *cu_seqlens, int n_sentences, int T, int n_head, unsigned *flags, unsigned *ranks, unsigned epoch0,
-                            unsigned rank0, int xcd, int *status, int *host_flag, hipStream_t stream, int H = 0, unsigned long long *timeline = nullptr);
 // Generic fallback (any K, N); needs W.naive16.
 void launch_gemm_naive(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C,
                        int M, int epilogue, hipStream_t stream);

@@ -17,9 +17,29 @@
 // (x + bo; b1; y + b2 resp. b2 with y added at the end for the features layer_tail's U wave owns), the same packed-f16
 // GELU on the same element pairs, and LayerNorm statistics summed in the order layer_tail's lanes and wave pairs sum them.
 // tests/test_gpu_parity.py::test_latency_route_gives_the_batch_route_s_bits holds the two routes against each other.
-#include "skinny_tile.h"
+#include "tile_stream.h"
 
 namespace bert_hip {
+
+namespace {
+
+enum SkinnyMode : int { SK_QKV = 0, SK_PROJ = 1, SK_UP = 2, SK_DOWN = 3 };
+
+struct SkinnyArgs {
+    const half_t *W;         // [N_pad][K] f16 (QKV, PROJ: GemmWeight::w16; UP, DOWN: w16p)
+    const half_t *A;         // [T_pad][K] f16 activations: QKV without LayerNorm: x; PROJ: ctx; DOWN: the GELU'ed intermediate,
+                             // stored in fragment order (see the UP epilogue)
+    const float *V;          // LayerNorm-fused forms (UP always, QKV from the second layer on): pre-LayerNorm values [T_pad][K] f32
+    const float *gamma, *beta;
+    half_t *ln_out;          // the LayerNorm'ed rows [T_pad][K] f16 (written by the workgroups of feature tile 0: the residual later)
+    const float *bias;       // [N]
+    const half_t *resid;     // PROJ: x [T_pad][N]; DOWN: y [T_pad][N]
+    half_t *out16;           // QKV: [T_pad][N]; UP: [T_pad][N] in fragment order
+    float *out32;            // PROJ, DOWN: [T_pad][N] pre-LayerNorm values
+    int N, K;
+};
+
+}  // namespace
 
 // grid = (N / 32 feature tiles, token blocks), block = 64: ONE wave per workgroup owns 32 tokens x 32 features (up to 192
 // workgroups at once for a 128-token sentence).  The tile's weight rows (32 x K halfs = 24 .. 96 KiB, one contiguous block)
@@ -38,9 +58,19 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
     // wave with its quarter of the token fragments requested at once, keeps the bits and costs 1.2 us per launch more.)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.x * 32, K = p.K, tok = blockIdx.y * 32 + l31;
+    const int n0 = blockIdx.x * 32, K = p.K, N = p.N, tok = blockIdx.y * 32 + l31;
+    const int cpr = K >> 3;                                   // 16-byte chunks per weight row (a multiple of 16)
 
-    skinny_request_weights(p.W + (size_t)n0 * K, K, smem, wave, n_waves, lane);
+    // ---- weights -> LDS: 16-byte unit u = row * cpr + c holds chunk (c & ~15) | ((c ^ row) & 15) of the row
+    {
+        const char *wbase = (const char *)(p.W + (size_t)n0 * K);
+        const int n_pieces = K >> 4;                          // 32 rows * K * 2 B / 1 KiB
+        for (int pc = wave; pc < n_pieces; pc += n_waves) {   // (every wave of the workgroup requests its share)
+            const int u = pc * 64 + lane, row = u / cpr, c = u - row * cpr;
+            const int src = (c & ~15) | ((c ^ row) & 15);
+            __builtin_amdgcn_global_load_lds(AS_GLOBAL(wbase + (size_t)row * K * 2 + src * 16), AS_LDS(smem + pc * 1024), 16, 0, 0);
+        }
+    }
     // ---- LN != 0: the 32 pre-LayerNorm rows -> LDS behind the weights, run (n, g) of all lanes = one 1 KiB piece (lane
     // (l31, hi): features 32 n + 8 g + 4 hi .. + 3 of its token).  In registers the row's 64 x H floats leave the compiler
     // no room to keep the parameter reads in flight (it waited for every pair in turn: 4 us per launch).
@@ -50,24 +80,63 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
         for (int pc = wave; pc < 16 * NT; pc += n_waves)
             __builtin_amdgcn_global_load_lds(AS_GLOBAL(vrow + (pc >> 2) * 128 + (pc & 3) * 32), AS_LDS(xl + pc * 1024), 16, 0, 0);
     }
-    auto landed = [&]() __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block (and the rows, the first fragments) have landed
-        __builtin_amdgcn_s_barrier();
-    };
-    if (wave != 0) { landed(); return; }
 
-    if constexpr (LN == 0) {
-        skinny_wave<MODE>(p, smem, n0, tok, lane, landed);
-    } else {
+    if (wave != 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ---- requested now, used behind the wait for the weight block (a load behind the MFMAs, or a wait for these values in
+    // front of the fragment requests, is a round trip of its own): bias and residual of the tile
+    f32x4 bias4[4];
+    [[maybe_unused]] f16x4 resid4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f = n0 + 8 * g + 4 * hi;
+        bias4[g] = *(const f32x4 *)(p.bias + f);
+        if constexpr (MODE == SK_PROJ || MODE == SK_DOWN) resid4[g] = *(const f16x4 *)(p.resid + (size_t)tok * N + f);
+    }
+    // the accumulators' initial value: register r = feature n0 + 8 (r >> 2) + 4 hi + (r & 3) of token `tok`
+    f32x16 acc;
+    auto form_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int f = n0 + 8 * g + 4 * hi;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE == SK_PROJ) {                  // x + bo (layer_tail.hip: accp)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (float)resid4[g][e] + bias4[g][e];
+            } else if constexpr (MODE == SK_UP) {             // b1 (layer_tail.hip: accU)
+                v = bias4[g];
+            } else if constexpr (MODE == SK_DOWN) {           // b2, + y for the features layer_tail's D wave owns (acc2)
+                v = bias4[g];
+                if ((f & 127) >= 64) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (float)resid4[g][e] + v[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g + e] = v[e];
+        }
+    };
+
+    const char *wl = smem + (size_t)l31 * cpr * 16;           // this lane's weight row in LDS
+    auto weight_frag = [&](int q) __attribute__((always_inline)) {
+        const int c = 2 * q + hi;
+        return *(const f16x8 *)(wl + (((c & ~15) | ((c ^ l31) & 15)) << 4));
+    };
+
+    if constexpr (LN != 0) {
         // ---- LayerNorm in registers, then k ascending over the whole row (K = H = 128 NT)
-        SkinnyEdge<MODE> edge;
-        edge.request(p, n0, tok, hi);
         f16x4 y[4 * NT][4];
         layernorm_runs_of<LN == 1, NT>(
             [&](int n, int g) __attribute__((always_inline)) { return *(const f32x4 *)(xl + (n * 4 + g) * 1024 + lane * 16); },
-            landed, p.gamma, p.beta, hi, y);
-        f32x16 acc;
-        edge.form_acc(acc, n0, hi);
+            [&]() __attribute__((always_inline)) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block and the rows have landed
+                __builtin_amdgcn_s_barrier();
+            },
+            p.gamma, p.beta, hi, y);
+        form_acc();
         if (blockIdx.x == 0) {
             half_t *orow = p.ln_out + (size_t)tok * K;
 #pragma unroll
@@ -77,6 +146,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
         }
 #pragma unroll
         for (int q = 0; q < 8 * NT; ++q) {
+            constexpr int dummy = 0; (void)dummy;
             const int n = q >> 1, s = q & 1;
             f16x8 b;
             if constexpr (MODE == SK_UP) {                    // fragment order = the runs' own order
@@ -91,9 +161,63 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { b[e] = lo[e]; b[4 + e] = up[e]; }
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(skinny_weight_frag(smem, K, l31, hi, q), b, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(weight_frag(q), b, acc, 0, 0, 0);
         }
-        edge.epilogue(p, acc, n0, tok, hi);
+    } else {
+        // ---- token fragments from memory: batches of 8 k-steps, four batches in flight
+        const half_t *arow = p.A + (size_t)tok * K + 8 * hi;
+        const int nb = K >> 7;
+        f16x8 b[4][8];
+        auto load_b = [&](auto slot_tag, int batch) __attribute__((always_inline)) {
+            constexpr int sl = decltype(slot_tag)::value;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) b[sl][u] = *(const f16x8 *)(arow + 16 * (batch * 8 + u));
+        };
+        static_for<4>([&](auto j_tag) __attribute__((always_inline)) { if (decltype(j_tag)::value < nb) load_b(j_tag, decltype(j_tag)::value); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the weight block has landed (and the first fragments)
+        __builtin_amdgcn_s_barrier();
+        form_acc();
+        for (int i0 = 0; i0 < nb; i0 += 4) {
+            static_for<4>([&](auto j_tag) __attribute__((always_inline)) {
+                constexpr int j = decltype(j_tag)::value;
+                const int batch = i0 + j;
+                if (batch < nb) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(weight_frag(batch * 8 + u), b[j][u], acc, 0, 0, 0);
+                    if (batch + 4 < nb) load_b(j_tag, batch + 4);
+                }
+            });
+        }
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int f = n0 + 8 * g + 4 * hi;
+        if constexpr (MODE == SK_QKV) {                       // acc + bias, one rounding (gemm.hip / qkv_attention2.hip)
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (_Float16)(acc[4 * g + e] + bias4[g][e]);
+            *(f16x4 *)(p.out16 + (size_t)tok * N + f) = o;
+        } else if constexpr (MODE == SK_UP) {                 // packed-f16 GELU of adjacent pairs (layer_tail.hip: gelu_pair)
+            const f16x2_t g0 = gelu_pk16(acc[4 * g], acc[4 * g + 1]), g1 = gelu_pk16(acc[4 * g + 2], acc[4 * g + 3]);
+            const f16x4 o = {g0[0], g0[1], g1[0], g1[1]};
+            // stored in FRAGMENT order: inside every group of 16 features the runs sit at [0-3, 8-11, 4-7, 12-15] (w16p's order),
+            // so that the down-projection's token fragment is one 16-byte load: run 8 (g & 1) + 4 hi of group g >> 1 goes
+            // to position 8 hi + 4 (g & 1)
+            *(f16x4 *)(p.out16 + (size_t)tok * N + n0 + 16 * (g >> 1) + 8 * hi + 4 * (g & 1)) = o;
+        } else {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
+            if constexpr (MODE == SK_DOWN) {                  // U's features: the residual comes last (layer_tail.hip, LayerNorm 2)
+                if ((f & 127) < 64) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)resid4[g][e];
+                }
+            }
+            *(f32x4 *)(p.out32 + (size_t)tok * N + f) = v;
+        }
     }
 }
 

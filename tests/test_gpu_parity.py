@@ -690,17 +690,14 @@ def test_legacy_q4_files_load_and_give_the_same_embeddings(tmp_path, ftype):
     assert np.array_equal(pybert.BertModel(cur).eval_batch(sents), pybert.BertModel(leg).eval_batch(sents))
 
 
-@pytest.mark.parametrize("mode", ["launches", "one_launch"])
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])
-def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype, mode):
-    """Batches of at most 128 tokens take the latency route: every mat-mul of a layer split by output features over many
-    workgroups instead of one workgroup per 128 tokens — as a launch per mat-mul (skinny.hip) or as ONE launch on the 32 CUs of
-    one XCD with team barriers between the phases (sentence_kernel.hip, the default).  A sentence's embedding must not depend
-    on what it is batched with, so both forms have to reproduce the fused kernels' arithmetic bit for bit: a sentence alone,
-    a few short sentences together, and the same sentences inside a large batch give identical bits."""
+def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype):
+    """Batches of at most 128 tokens take the latency route (skinny.hip: every mat-mul of a layer split by output features
+    over many workgroups instead of one workgroup per 128 tokens).  A sentence's embedding must not depend on what it is
+    batched with, so the route has to reproduce the fused kernels' arithmetic bit for bit: a sentence alone, a few short
+    sentences together, and the same sentences inside a large batch give identical bits."""
     path, hp = make_model("minilm-l6", ftype, 0)
     m = pybert.BertModel(path)
-    m.set_option("latency", "1" if mode == "launches" else "2")
     rng = np.random.default_rng(11)
     lens = [128, 25, 1, 77, 33, 96, 64, 5, 127, 32, 31]
     sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in lens]
@@ -711,12 +708,8 @@ def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype, mode):
     names_alone = set(m.profile_report())
     few = m.eval_batch([sents[1], sents[2], sents[7], sents[4], sents[10]])      # 95 tokens, five sentences
     m.profile(False)
-    assert {"qkv_attention2", "layer_tail"} <= names_batch and not any(k.startswith("skinny") or k == "sentence_kernel" for k in names_batch), names_batch
-    if mode == "launches":
-        assert {"skinny_qkv", "skinny_proj", "skinny_ffn_up", "skinny_ffn_down", "skinny_layernorm", "attention"} <= names_alone, names_alone
-    else:
-        assert "sentence_kernel" in names_alone and not any(k.startswith("skinny") for k in names_alone), names_alone
-        assert m.check() == 0                                 # (no barrier gave up)
+    assert {"qkv_attention2", "layer_tail"} <= names_batch and not any(k.startswith("skinny") for k in names_batch), names_batch
+    assert {"skinny_qkv", "skinny_proj", "skinny_ffn_up", "skinny_ffn_down", "skinny_layernorm", "attention"} <= names_alone, names_alone
     for i, a in enumerate(alone):
         assert np.array_equal(a, batch[i]), (ftype, lens[i], float(np.abs(a - batch[i]).max()))
     for k, i in enumerate([1, 2, 7, 4, 10]):

@@ -1,11 +1,13 @@
 #!/bin/bash
 export TMPDIR=/tmp BERT_HIP_QUIET=1
-for lib in f1; do
-BERT_HIP_SK1_TIMELINE=1 BERT_HIP_LIB=${lib:+$PWD/bert.cpp_amd/libbert_$lib.so} BERT_HIP_LATENCY=2 timeout 200 python - <<'PY' 2>&1 | grep -v "^$" | cut -c1-1500 | head -9
+timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_exactness.py -x -q -m gpu -k "latency or skinny or route" 2>&1 | tail -5
+for i in 1 2; do
+timeout 200 python - <<'PY'
 import os, sys, tempfile
 sys.path.insert(0, os.getcwd())
 import bench
 with tempfile.TemporaryDirectory() as d:
-    r = bench.latency_b1(d, calls=100)
+    r = bench.latency_b1(d, calls=400)
+    print({k: round(v["median_us"], 1) for k, v in r.items() if isinstance(v, dict)}, r["f16_n128"]["kernel_us"])
 PY
 done

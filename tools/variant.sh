@@ -7,7 +7,7 @@ name=$1; src=$2; flags=$3
 make -s libbert.so >/dev/null
 mkdir -p build_var
 obj=build_var/${name}_$(basename ${src%.hip}).o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -mllvm -structurizecfg-skip-uniform-regions=true -mllvm -amdgpu-mfma-vgpr-form $flags -c csrc/$src -o $obj
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -mllvm -structurizecfg-skip-uniform-regions=true $flags -c csrc/$src -o $obj
 objs=$(ls build/*.o | grep -v "build/$(basename ${src%.hip}).o" | grep -v build/test_api.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libbert_${name}.so $objs $obj -ldl -lpthread
 echo "built bert.cpp_amd/libbert_${name}.so"
