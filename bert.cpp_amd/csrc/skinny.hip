@@ -25,8 +25,10 @@ namespace {
 
 enum SkinnyMode : int { SK_QKV = 0, SK_PROJ = 1, SK_UP = 2, SK_DOWN = 3 };
 
+// (the weight matrix W [N_pad][K] f16 — QKV, PROJ: GemmWeight::w16; UP, DOWN: w16p — K, N and the workgroup's wave count are
+// kernel arguments of their own, in front: the first sixteen dwords of the arguments are preloaded into SGPRs at dispatch
+// (-mllvm -amdgpu-kernarg-preload-count), so the weight block is requested without waiting for a load of the arguments)
 struct SkinnyArgs {
-    const half_t *W;         // [N_pad][K] f16 (QKV, PROJ: GemmWeight::w16; UP, DOWN: w16p)
     const half_t *A;         // [T_pad][K] f16 activations: QKV without LayerNorm: x; PROJ: ctx; DOWN: the GELU'ed intermediate,
                              // stored in fragment order (see the UP epilogue)
     const float *V;          // LayerNorm-fused forms (UP always, QKV from the second layer on): pre-LayerNorm values [T_pad][K] f32
@@ -36,7 +38,6 @@ struct SkinnyArgs {
     const half_t *resid;     // PROJ: x [T_pad][N]; DOWN: y [T_pad][N]
     half_t *out16;           // QKV: [T_pad][N]; UP: [T_pad][N] in fragment order
     float *out32;            // PROJ, DOWN: [T_pad][N] pre-LayerNorm values
-    int N, K;
 };
 
 }  // namespace
@@ -51,19 +52,19 @@ struct SkinnyArgs {
 //   (layer_tail.hip's trick: w16p); for the QKV projection of the next layer (plain k order) the two lane halves swap one
 //   run per k-step.  The workgroups of feature tile 0 write the normalised rows for their later use as residual.
 template <int MODE, int LN, int NT>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyArgs p) {
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const half_t *__restrict__ W, int K, int N, int n_waves, SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // wave 0 owns the tile; waves 1 .. only help to request the weight block (one wave issues a 96 KiB block in 2.8 us,
     // four in 0.7) and leave at the barrier.  (The down-projection's k range handed from wave to wave through LDS, every
     // wave with its quarter of the token fragments requested at once, keeps the bits and costs 1.2 us per launch more.)
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int n0 = blockIdx.x * 32, K = p.K, N = p.N, tok = blockIdx.y * 32 + l31;
+    const int n0 = blockIdx.x * 32, tok = blockIdx.y * 32 + l31;
     const int cpr = K >> 3;                                   // 16-byte chunks per weight row (a multiple of 16)
 
     // ---- weights -> LDS: 16-byte unit u = row * cpr + c holds chunk (c & ~15) | ((c ^ row) & 15) of the row
     {
-        const char *wbase = (const char *)(p.W + (size_t)n0 * K);
+        const char *wbase = (const char *)(W + (size_t)n0 * K);
         const int n_pieces = K >> 4;                          // 32 rows * K * 2 B / 1 KiB
         for (int pc = wave; pc < n_pieces; pc += n_waves) {   // (every wave of the workgroup requests its share)
             const int u = pc * 64 + lane, row = u / cpr, c = u - row * cpr;
@@ -247,15 +248,15 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
                         half_t *ln_out, const float *bias, const half_t *resid, half_t *out16, float *out32, int n_token_blocks,
                         hipStream_t stream) {
     SkinnyArgs a;
-    a.W = (mode == SK_UP || mode == SK_DOWN) ? W.w16p : W.w16;
+    const half_t *w = (mode == SK_UP || mode == SK_DOWN) ? W.w16p : W.w16;
     a.A = A; a.V = V; a.gamma = gamma; a.beta = beta; a.ln_out = ln_out;
-    a.bias = bias; a.resid = resid; a.out16 = out16; a.out32 = out32; a.N = W.N; a.K = W.K;
+    a.bias = bias; a.resid = resid; a.out16 = out16; a.out32 = out32;
     const dim3 grid(W.N / 32, n_token_blocks), block(W.K >= 1024 ? 256 : 128);     // wave 0 computes, the others help to request the weights
     const size_t lds = (size_t)32 * W.K * 2 + (V ? (size_t)32 * W.K * 4 : 0);     // the tile's weight rows (+ the pre-LayerNorm rows)
     static DeviceFlags configured[8];
     auto go = [&](auto kernel, int m) {
         if (lds > 64 * 1024) configure_once(configured[m], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        BERT_LAUNCH(kernel, grid, block, lds, stream, a);
+        BERT_LAUNCH(kernel, grid, block, lds, stream, w, W.K, W.N, (int)(block.x / 64), a);
     };
     const bool nt2 = W.K == 256;                             // (only the LayerNorm-fused forms depend on NT: K = H there)
     switch (mode) {
