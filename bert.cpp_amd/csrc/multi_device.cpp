@@ -171,8 +171,22 @@ bool RcclGather::init(const std::vector<int> &devices, std::string &err) {
         for (auto &f : fn_) f = nullptr;
         return false;
     };
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        lib_ = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // The RCCL that belongs to the HIP runtime this process runs on: the one next to the loaded libamdhip64.  A process can
+    // hold two (a PyTorch wheel brings its own ROCm libraries; "librccl.so" by name then resolves to whichever was loaded
+    // first, and a librccl of another ROCm release on this runtime fails in ncclCommInitAll with "unhandled cuda error").
+    std::vector<std::string> candidates;
+    Dl_info hip_lib;
+    if (dladdr((const void *)&hipGetDeviceCount, &hip_lib) && hip_lib.dli_fname) {
+        const std::string path = hip_lib.dli_fname;
+        const size_t slash = path.rfind('/');
+        if (slash != std::string::npos) {
+            candidates.push_back(path.substr(0, slash) + "/librccl.so");
+            candidates.push_back(path.substr(0, slash) + "/librccl.so.1");
+        }
+    }
+    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) candidates.push_back(name);
+    for (const std::string &name : candidates) {
+        lib_ = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (lib_) break;
     }
     if (!lib_) { err = std::string("cannot load librccl.so: ") + dlerror(); return false; }
