@@ -124,7 +124,12 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
     if (m.pooled) {
         const int tid = thread_id();
         for (int j = 0; j < count; ++j) {
-            const int b = first + j, t0 = m.cu[b], n = m.cu[b + 1] - t0;
+            const int b = first + j, t0 = m.cu[b];
+            int n = m.cu[b + 1] - t0;
+            // (the full-window form computed rows 128 b .. 128 b + 127 as ONE sentence: in a batch that has this shape only by the
+            // sum of its lengths — somebody longer than max_len = 128, somebody shorter — a sentence that is not exactly that block
+            // gets the NaN row and the status word of the length guard instead of numbers made of its neighbours' tokens)
+            if (!RAGGED && (t0 != tok0 || n != 128)) n = -1;
             pool_normalize_sentence(m.x, t0, n, b, 128 * NT, m.max_len, m.status, m.pooled, (float *)smem, tid, tid < 256);
             __syncthreads();                                  // (the next sentence reuses the partial rows)
         }

@@ -67,10 +67,10 @@ BERT_API int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vo
  *   - the workspace grows on demand, and growing allocates (synchronises the device, illegal under stream capture):
  *     call bert_hip_reserve once with the largest batch first;
  *   - lengths are validated on the device: a sentence longer than max_len (or empty) yields a NaN embedding and sets a
- *     status word that bert_hip_check returns (and clears) after synchronising.  When the status word is set, only the
- *     rows of sentences that kept the promise AND do not share a 128-token block of the packed batch with an offender are
- *     meaningful: a batch shaped like full windows (n_tokens_total = 128 n_sentences, max_len = 128) is evaluated block by
- *     block, and an over-long sentence shifts its neighbours across block boundaries;
+ *     status word that bert_hip_check returns (and clears) after synchronising.  A batch shaped like full windows
+ *     (n_tokens_total = 128 n_sentences, max_len = 128) is evaluated 128-token block by block: if it has that shape only by
+ *     the sum of its lengths (an over-long sentence, a shorter one), every sentence that is not exactly its block gets a
+ *     NaN row as well — the other rows are the bits they always have;
  *   - short sentences are packed several to a 128-slot attention window by a kernel of the pass itself (the lengths
  *     exist only in HBM here): results are the bits of the host entry points.                                        */
 BERT_API int32_t bert_hip_eval_packed_device(struct bert_ctx *ctx, const bert_vocab_id *d_tokens,

@@ -201,6 +201,20 @@ def test_device_api_guards(make_model, capfd, one_launch):
     got2 = hip.download(out2, (6, H))
     assert np.isnan(got2[1]).all() and np.array_equal(got2[[0, 2, 3, 4, 5]], want2)
     capfd.readouterr()
+    # a batch that LOOKS like full windows (T = 128 B, max_len = 128) but is not: the form specialised for full windows works
+    # 128-token block by block — the sentences that are exactly their block keep their bits, every other one (the offender and
+    # the neighbours it shifts across block boundaries) gets a NaN row, none gets numbers made of a neighbour's tokens
+    lens3 = [128, 128, 200, 56, 128]
+    cu3 = _cu(lens3)
+    assert int(cu3[-1]) == 128 * len(lens3)
+    toks3 = np.random.default_rng(2).integers(1000, hp.n_vocab, size=int(cu3[-1])).astype(np.int32)
+    want3 = m.eval_batch([toks3[cu3[i]:cu3[i + 1]] for i in (0, 1, 4)])
+    out3 = hip.upload(np.full((5, H), 7.0, np.float32))
+    m.eval_packed_device(hip.upload(toks3), hip.upload(cu3), 5, int(cu3[-1]), 128, out3, 0)
+    assert m.check() == 1
+    got3 = hip.download(out3, (5, H))
+    assert np.isnan(got3[2]).all() and np.isnan(got3[3]).all() and np.array_equal(got3[[0, 1, 4]], want3)
+    capfd.readouterr()
     # two streams, back to back: the context serialises its passes itself
     s1, s2 = hip.stream(), hip.stream()
     o1, o2 = hip.malloc(4 * H * 4), hip.malloc(4 * H * 4)
