@@ -546,8 +546,21 @@ def run_inproc(args):
             res["out"] = None
             base, mc, mn, _ = cpu_baseline_and_cosine(dict(res, cu=cu[:min(B, 64) + 1], tokens=int(cu[min(B, 64)])), budget_s=12.0, gpu=host)
             line.update(cpu_baseline=base, mean_cosine_vs_cpu=mc, min_cosine_vs_cpu=mn, speedup_vs_cpu=line["value"] / base["value"])
-        print(json.dumps(line))
+        emit_line(line)
         m.close()
+
+
+def emit_line(line):
+    """The ONE JSON line, as the LAST line of stdout: whatever native libraries have printed through C stdio so far (RCCL writes
+    a version banner at its first communicator: the in-process gather entry) sits in C's buffer and would otherwise come out
+    at exit, behind Python's own buffer."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
 
 
 def main():
@@ -670,7 +683,7 @@ def main():
                     line["summary"][k] = {"texts_per_s": round(v["value"], 1), "mean_tokens_per_text": round(v["mean_tokens_per_text"], 1)}
                 else:
                     line["summary"][k] = brief(v)
-            print(json.dumps(line))
+            emit_line(line)
     if world > 1:
         dist.destroy_process_group()
 
