@@ -667,13 +667,14 @@ def test_legacy_q4_files_load_and_give_the_same_embeddings(tmp_path, ftype):
     assert np.array_equal(pybert.BertModel(cur).eval_batch(sents), pybert.BertModel(leg).eval_batch(sents))
 
 
-@pytest.mark.parametrize("ftype", ["f16", "q4_0"])
-def test_latency_route_gives_the_batch_route_s_bits(make_model, ftype):
+@pytest.mark.parametrize("dims,ftype", [("minilm-l6", "f16"), ("minilm-l6", "q4_0"), ("h256-l3", "f16")])
+def test_latency_route_gives_the_batch_route_s_bits(make_model, dims, ftype):
     """Batches of at most 128 tokens take the latency route (skinny.hip: every mat-mul of a layer split by output features
     over many workgroups instead of one workgroup per 128 tokens).  A sentence's embedding must not depend on what it is
     batched with, so the route has to reproduce the fused kernels' arithmetic bit for bit: a sentence alone, a few short
     sentences together, and the same sentences inside a large batch give identical bits."""
-    path, hp = make_model("minilm-l6", ftype, 0)
+    gf.MODEL_DIMS.setdefault("h256-l3", gf.BertHParams(1000, 128, 256, 1024, 8, 3))      # (H = 256: the NT = 2 forms of the kernels)
+    path, hp = make_model(dims, ftype, 0)
     m = pybert.BertModel(path)
     rng = np.random.default_rng(11)
     lens = [128, 25, 1, 77, 33, 96, 64, 5, 127, 32, 31]
