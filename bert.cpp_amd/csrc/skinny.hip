@@ -42,13 +42,14 @@ struct SkinnyArgs {
 
 }  // namespace
 
-// grid = (N / 32 feature tiles, token blocks), block = 64: ONE wave per workgroup owns 32 tokens x 32 features (up to 192
-// workgroups at once for a 128-token sentence).  The tile's weight rows (32 x K halfs = 24 .. 96 KiB, one contiguous block)
+// grid = (N / 32 feature tiles, token blocks), block = 128 or 256: ONE wave of the workgroup owns 32 tokens x 32 features (up to
+// 192 workgroups at once for a 128-token sentence), the others only request their share of the LDS-DMA pieces.  The tile's weight rows (32 x K halfs = 24 .. 96 KiB, one contiguous block)
 // come in by LDS-DMA in one round trip — fully coalesced 1 KiB pieces, the 16-byte chunk of a row XOR-swizzled on the
 // source side so that the fragment reads are conflict-free.  The token operand:
 //   LN == 0: 16-byte fragments straight from HBM / L2 (x in the first layer, ctx, the intermediate in fragment order);
-//   LN != 0: the workgroup LayerNorms its 32 rows itself (redundantly per feature tile: 1 us of arithmetic) from the f32
-//   values the kernel before left — for the up-projection the normalised runs in their registers ARE its fragments
+//   LN != 0: the workgroup LayerNorms its 32 rows itself (redundantly per feature tile: 1 us of arithmetic; sharing the
+//   rows among four tiles of a workgroup was measured: slower) from the f32 values the kernel before left, which arrive by
+//   LDS-DMA behind the weight block — for the up-projection the normalised runs in their registers ARE its fragments
 //   (layer_tail.hip's trick: w16p); for the QKV projection of the next layer (plain k order) the two lane halves swap one
 //   run per k-step.  The workgroups of feature tile 0 write the normalised rows for their later use as residual.
 template <int MODE, int LN, int NT>
