@@ -53,7 +53,7 @@ struct SkinnyArgs {
 //   (layer_tail.hip's trick: w16p); for the QKV projection of the next layer (plain k order) the two lane halves swap one
 //   run per k-step.  The workgroups of feature tile 0 write the normalised rows for their later use as residual.
 template <int MODE, int LN, int NT>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const half_t *__restrict__ W, int K, int N, int n_waves, SkinnyArgs p) {
+__global__ __launch_bounds__(512) void skinny_gemm_kernel(const half_t *__restrict__ W, int K, int N, int n_waves, SkinnyArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // wave 0 owns the tile; waves 1 .. only help to request the weight block (one wave issues a 96 KiB block in 2.8 us,
     // four in 0.7) and leave at the barrier.  (The down-projection's k range handed from wave to wave through LDS, every
@@ -252,7 +252,9 @@ void launch_skinny_gemm(int mode, const GemmWeight &W, const half_t *A, const fl
     const half_t *w = (mode == SK_UP || mode == SK_DOWN) ? W.w16p : W.w16;
     a.A = A; a.V = V; a.gamma = gamma; a.beta = beta; a.ln_out = ln_out;
     a.bias = bias; a.resid = resid; a.out16 = out16; a.out32 = out32;
-    const dim3 grid(W.N / 32, n_token_blocks), block(W.K >= 1024 ? 256 : 128);     // wave 0 computes, the others help to request the weights
+    // eight waves per workgroup: wave 0 computes, ALL of them request their share of the LDS-DMA pieces (24 .. 96 of 1 KiB) —
+    // two, four, eight request waves: 232, 229, 219 us per 128-token call (profiles/r4_experiments.txt): more requests in flight
+    const dim3 grid(W.N / 32, n_token_blocks), block(512);     
     const size_t lds = (size_t)32 * W.K * 2 + (V ? (size_t)32 * W.K * 4 : 0);     // the tile's weight rows (+ the pre-LayerNorm rows)
     static DeviceFlags configured[8];
     auto go = [&](auto kernel, int m) {

@@ -113,7 +113,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *                          same bits on the fused kernels; a quarter of the weight bytes)
  *   BERT_HIP_LATENCY       1 (default) | 0 — batches of at most 128 tokens (one sentence per call, the reference's callers) take the
  *                          latency route: every mat-mul of a layer split over up to 192 workgroups (skinny.hip); same bits
- *                          (240 us per 128-token sentence, host to host)
+ *                          (220 us per 128-token sentence, host to host)
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
