@@ -231,3 +231,53 @@ def test_legacy_q4_block_layout_is_detected_and_converted(tmp_path, ftype):
     with silenced_stderr():
         with pytest.raises(RuntimeError):
             libbert.model_digest(bad)
+
+
+def test_bench_line_stays_parseable_for_the_driver():
+    """Round 4's line was 26 kB and the driver could not parse it.  The compact line built from that
+    very round's full result (profiles/r4_bench_line.json: twelve entries under `also`) must stay under 6 kB, keep the
+    contract keys, `roofline` and `cpu_baseline`, and round-trip through json."""
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r4_bench_line.json")) as f:
+        full = json.load(f)
+    contract_keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                     "dtype", "data", "config")
+    contract = {k: full[k] for k in contract_keys}
+    e = dict(full)
+    e["eval_batch_api"] = {"value": 300000.123456, "ms_per_call": 0.85333333, "vs_eval_packed": 0.99123456, "rows_equal_eval_packed": True}
+    extras = dict(full["also"])
+    extras["broken_entry"] = {"workload": "x", "error": "RuntimeError: " + "y" * 1000}
+    line = bench.compact_line(contract, e, extras, "/some/where/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) < bench.LINE_LIMIT == 6144, len(text)
+    back = json.loads(text)
+    for k in contract_keys + ("roofline", "cpu_baseline", "host_to_host", "eval_batch_api", "also", "mean_cosine_vs_cpu"):
+        assert k in back, k
+    assert back["roofline"]["bound"] == "mfma" and 0 < back["roofline"]["frac"] < 1 and back["roofline"]["traffic"] > 0
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(back["cpu_baseline"])
+    assert set(extras) == set(back["also"])
+    for k, v in back["also"].items():
+        assert len(v) <= 12, (k, v)
+    # every value of the headline survives to 6 digits
+    assert abs(back["value"] - full["value"]) < 1e-6 * full["value"]
+    # a pathological input (every entry an error, long strings) still gives a parseable, short line
+    worst = bench.compact_line(contract, e, {f"entry{i}": {"error": "z" * 5000} for i in range(40)}, None)
+    assert len(json.dumps(worst)) < bench.LINE_LIMIT
+
+
+def test_library_exports_nothing_but_the_c_abi():
+    """A drop-in for the reference's libbert.so (reference bert.h:8-16: BERT_API on its 11 functions) exports those names and the
+    bert_hip_* extensions — no kernel stubs, no __hip_cuid_*, no weak libstdc++ instantiations (bert.cpp_amd/libbert.map)."""
+    import subprocess
+
+    def exported(path):
+        out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+        return sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+
+    assert exported(libbert.LIB_PATH) == sorted(libbert.BERT_H_SYMBOLS + libbert.BERT_HIP_H_SYMBOLS)
+    assert exported(libbert.TEST_LIB_PATH) == sorted(libbert.BERT_H_SYMBOLS + libbert.BERT_HIP_H_SYMBOLS + libbert.BERT_HIP_TEST_H_SYMBOLS)
