@@ -19,6 +19,8 @@
 // Sequences longer than 128 keys stream over 128-key chunks with an online softmax.
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace bert_hip {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -34,6 +36,54 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
     if (D == 32) return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
+
+// ---- the chunk loop's issue plan (compile time) --------------------------------------------------------------------
+// One wave works through a 128-key chunk as: S^T (KT * D/16 MFMAs), softmax (VALU), O^T += V^T P^T (KT * 2 * D/32 MFMAs).
+// Issued in that order — rounds 1-4 — the matrix pipe idles through the softmax and the VALU through both mat-muls of the
+// wave, two waves per SIMD overlap only where they happen to be out of step, and every MFMA waits for a fragment requested
+// one MFMA earlier (512 x 512 tokens, d_head 64: MFMA busy 27 %, 743 us; profiles/r4_pmc.txt).  Round 5 software-pipelines
+// the loop INSIDE the wave: while the softmax of chunk i runs, the wave issues the S^T MFMAs of chunk i + 1 (into a second
+// set of score registers) and the P·V MFMAs of the key tile whose numerators were finished one step earlier.  The body is a
+// list of GROUPS, each = at most one MFMA + one piece of VALU work, in the program order below (sched_barrier between
+// groups: the machine scheduler may not regroup them); an MFMA's LDS fragment is requested PIPE_RING - 1 MFMAs ahead.
+//   key tile kt = 0..3:  MFMAs  S(i+1)[kt] k-step 0, P·V(kt-1) step 0, S(i+1)[kt] k-step 1, P·V(kt-1) step 1, ...
+//                        VALU   arguments(kt, keys 0-15) | exponentials | row sum + arguments(keys 16-31) | exponentials | row sum
+//   tail:                MFMAs  P·V(3) ...               VALU   in-lane maximum of S(i+1), one tile per group
+// The arithmetic per score is unchanged (softmax_args4 / _exp4 / _sum4 are softmax_p8's three steps, kernels.h; the row sum runs
+// over the pairs in the same order): the same bits as the straight-line form and as qkv_attention2.hip.
+struct PipeOp { int type, kt, idx; };          // type 1: S tile kt of the NEXT chunk, k-step idx; 2: P·V of key tile kt, step idx = st * DV + dv
+struct PipeGroup { int op, piece_kt, piece; }; // op: index into ops, or -1; piece 0..4 of key tile piece_kt (piece_kt 4: maximum of next tile `piece`), or -1
+constexpr int PIPE_RING = 4;
+template <int D, bool NEXT>
+struct PipePlan {
+    static constexpr int KS = D / 16, PVN = 2 * (D / 32);
+    PipeOp ops[64];
+    PipeGroup g[64];
+    int n_ops, n;
+    constexpr PipePlan() : ops{}, g{}, n_ops(0), n(0) {
+        for (int kt = 0; kt <= 4; ++kt) {
+            PipeOp list[16] = {};
+            int nl = 0;
+            const int ns = (NEXT && kt < 4) ? KS : 0, np = kt >= 1 ? PVN : 0;
+            for (int i = 0; i < (ns > np ? ns : np); ++i) {
+                if (i < ns) list[nl++] = PipeOp{1, kt, i};
+                if (i < np) list[nl++] = PipeOp{2, kt - 1, i};
+            }
+            const int npiece = kt < 4 ? 5 : (NEXT ? 4 : 0);
+            const int ng = nl > npiece ? nl : npiece;
+            int placed = 0;
+            for (int i = 0; i < ng; ++i) {
+                PipeGroup x{-1, kt, i < npiece ? i : -1};
+                // the MFMAs of this key tile spread evenly over its groups
+                if (placed < nl && i * nl >= placed * ng) {
+                    x.op = n_ops;
+                    ops[n_ops++] = list[placed++];
+                }
+                g[n++] = x;
+            }
+        }
+    }
+};
 
 // NT threads: 256 (4 waves), or 512 for long sentences (their K / V^T fill most of the CU's LDS, so one workgroup is all
 // a CU holds: 8 waves = two per SIMD let one wave's softmax run under the other's MFMAs).  CH = keys per online-softmax
@@ -149,78 +199,135 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
         constexpr int K_ROW = D * 2;                   // bytes per K row
 
         constexpr int KT = CH / 32;                    // key tiles per step
+        static_assert(KT == 4, "the issue plan is written for 128-key chunks");
+        constexpr int DV = D / 32, KS = D / 16;
+        constexpr bool PIPE = NT > 256;                // sentences of more than one chunk exist only in the 8-wave form
         const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
-        for (int kc = 0; kc < n_steps; kc += CH) {
-            // ---- S^T chunk: KT key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
-            f32x16 s[KT];
+        typedef const __attribute__((address_space(3))) f16x8 *lds_f16x8;
+        typedef const __attribute__((address_space(3))) f16x4 *lds_f16x4;
+
+        // ---- prologue: S^T of the first chunk; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
+        f32x16 s[KT];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
+        for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int kk = 0; kk < D / 16; ++kk) {
-                    const f16x8 kf = *(const __attribute__((address_space(3))) f16x8 *)(kbase[kk] + kt * 32 * K_ROW);
-                    // (the first k-step starts from the constant 0: no zeroing moves)
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
-                }
+            for (int kk = 0; kk < KS; ++kk) {
+                const f16x8 kf = *(lds_f16x8)(kbase[kk] + kt * 32 * K_ROW);
+                // (the first k-step starts from the constant 0: no zeroing moves)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
             }
 #pragma unroll
-            for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
-            // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
-            if (kc + CH > n) {
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        s[kt][r] = key < n ? s[kt][r] : -INFINITY;
-                    }
-            }
-            float mx = -INFINITY;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit; the exponent below is one
-            // fma per score (the same arithmetic as qkv_attention2.hip: equal bits across the kernels)
-            const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
-            float psum = 0.f;
+        for (int kk = 0; kk < KS; ++kk) kbase[kk] += CH * K_ROW;        // kbase: the NEXT chunk's K rows
+        // the ragged tail of a chunk (only a sentence's last chunk can have one) -> -inf; in-lane maximum of the raw scores
+        auto mask_tail = [&](f32x16 (&t)[KT], int kc) __attribute__((always_inline)) {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -m_new));
-                    s[kt][r] = pv;
-                    psum += pv;
+                    const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    t[kt][r] = key < n ? t[kt][r] : -INFINITY;
                 }
+        };
+        auto tile_max = [&](const f32x16 &t, float mx) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(t[r], t[r + 1]), mx);   // v_max3_f32
+            return mx;
+        };
+        // (the volatile asm keeps the rare path a real branch: if-converted, its 64 compares and selects run in every chunk)
+        if (CH > n) { asm volatile("; ragged first chunk" ::: "memory"); mask_tail(s, 0); }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) mx = tile_max(s[kt], mx);
+
+        // ---- one chunk: softmax of s, O^T += V^T P^T; NEXT: S^T of the following chunk computed underneath (-> s, mx)
+        // (s: the chunk's scores; sn receives the following chunk's — the loop below alternates two register sets, a copy
+        // sn -> s at the end of every chunk would be 32 v_mov_b64 behind an MFMA-result wait)
+        auto chunk = [&](auto next_tag, int kc, f32x16 (&s)[KT], f32x16 (&sn)[KT]) __attribute__((always_inline)) {
+            constexpr bool NEXT = decltype(next_tag)::value;
+            static constexpr PipePlan<D, NEXT> plan{};
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit
+            const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
+#pragma unroll
+            for (int dv = 0; dv < DV; ++dv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+            float psum = 0.f, mxn = -INFINITY;
+            u32x4_t aa[KT][2], pp[KT][2];
+            f16x8 fr[PIPE_RING];
+            auto fragment = [&](const PipeOp op) __attribute__((always_inline)) -> f16x8 {
+                if (op.type == 1) return *(lds_f16x8)(kbase[op.idx] + op.kt * 32 * K_ROW);
+                // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
+                const lds_halfs vr = vbase[op.idx % DV] + op.kt * 32 + 16 * (op.idx / DV);
+                const f16x4 v0 = *(lds_f16x4)vr, v1 = *(lds_f16x4)(vr + 8);
+                return f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            };
+#pragma unroll
+            for (int j = 0; j < PIPE_RING - 1; ++j)
+                if (j < plan.n_ops) fr[j % PIPE_RING] = fragment(plan.ops[j]);
+#pragma unroll
+            for (int gi = 0; gi < plan.n; ++gi) {
+                const PipeGroup G = plan.g[gi];
+                if (G.op >= 0) {
+                    const PipeOp op = plan.ops[G.op];
+                    if (G.op + PIPE_RING - 1 < plan.n_ops) fr[(G.op + PIPE_RING - 1) % PIPE_RING] = fragment(plan.ops[G.op + PIPE_RING - 1]);
+                    const f16x8 af = fr[G.op % PIPE_RING];
+                    if (op.type == 1)
+                        sn[op.kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[op.idx], op.idx == 0 ? (f32x16)0.f : sn[op.kt], 0, 0, 0);
+                    else
+                        o[op.idx % DV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, pp[op.kt][op.idx / DV]), o[op.idx % DV], 0, 0, 0);
+                }
+                if (G.piece >= 0) {
+                    const int kt = G.piece_kt, st = G.piece >= 2;
+                    // (the empty volatile asm statements pin a piece's results to its group: pure operations carry no order
+                    // against sched_barrier before the machine scheduler sees them — left alone the row-sum dot products and
+                    // the maxima of the next chunk sink to the end of the block, out from under the MFMAs)
+                    if (kt == 4) {
+                        mxn = tile_max(sn[G.piece], mxn);
+                        asm volatile("" : "+v"(mxn));
+                    } else {
+                        if (G.piece == 2 || G.piece == 4) {
+                            softmax_sum4(pp[kt][G.piece == 4], psum);
+                            asm volatile("" : "+v"(psum));
+                        }
+                        if (G.piece == 0 || G.piece == 2) {
+                            aa[kt][st] = softmax_args4(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
+                                                       s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new);
+                            asm volatile("" : "+v"(aa[kt][st]));
+                        }
+                        if (G.piece == 1 || G.piece == 3) {
+                            pp[kt][G.piece == 3] = softmax_exp4(aa[kt][G.piece == 3]);
+                            asm volatile("" : "+v"(pp[kt][G.piece == 3]));
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             psum += __shfl_xor(psum, 32);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
-            for (int dv = 0; dv < D / 32; ++dv)
+            for (int dv = 0; dv < DV; ++dv) vbase[dv] += CH;
+            if constexpr (NEXT) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
-            // ---- O^T += V^T * P^T
+                for (int kk = 0; kk < KS; ++kk) kbase[kk] += CH * K_ROW;
+                mx = mxn;
+                if (kc + 2 * CH > n) {                   // the following chunk is the sentence's ragged last one
+                    asm volatile("; ragged last chunk" ::: "memory");
+                    mask_tail(sn, kc + CH);
+                    mx = -INFINITY;
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    f16x8 pf;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pf[e] = (_Float16)s[kt][8 * st + e];
-                    // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
-#pragma unroll
-                    for (int dv = 0; dv < D / 32; ++dv) {
-                        const lds_halfs vr = vbase[dv] + kt * 32 + 16 * st;
-                        const f16x4 v0 = *(const __attribute__((address_space(3))) f16x4 *)vr, v1 = *(const __attribute__((address_space(3))) f16x4 *)(vr + 8);
-                        f16x8 vf;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
-                        o[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dv], 0, 0, 0);
-                    }
+                    for (int kt = 0; kt < KT; ++kt) mx = tile_max(sn[kt], mx);
                 }
-#pragma unroll
-            for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += CH;
+            }
+        };
+        f32x16 s2[KT];
+        for (int kc = 0;; kc += 2 * CH) {
+            if (!(PIPE && kc + CH < n_steps)) { chunk(std::false_type{}, kc, s, s2); break; }
+            chunk(std::true_type{}, kc, s, s2);
+            if (!(kc + 2 * CH < n_steps)) { chunk(std::false_type{}, kc + CH, s2, s); break; }
+            chunk(std::true_type{}, kc + CH, s2, s);
         }
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
         const int q = qb * 32 + l31;

@@ -24,6 +24,80 @@ __device__ __forceinline__ float rounded_f32(float v) {
 }
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+// Softmax numerators of EIGHT scores of one query (registers 8 st .. 8 st + 7 of an S^T tile = the B fragment of one P·V MFMA
+// step), in the reference's own precision: ggml's soft_max rounds (s - max) to fp16 and reads an fp16 table of exp
+// (reference bert.cpp:845 -> ggml_soft_max; oracle/bert_oracle.cpp:544), sums in higher precision and rounds P to f16 again
+// for the V mat-mul.  Here: the argument s * sc - m is ONE fma rounded once to f16 (v_fma_mixlo / mixhi_f16 write the two
+// halves of a register: no conversion instruction), the exponential is v_exp_f16 on each half (the high one through SDWA with
+// the low half preserved: no pack), the pair IS the MFMA operand, and the row sum stays f32 (v_dot2c_f32_f16 with (1, 1): one
+// instruction per pair).  16 VALU + 4 dot2 per 8 scores against 28 for fma / v_exp_f32 / add / v_cvt_pk_f16_f32 — the attention
+// waves are VALU-bound.  All attention bodies (attention.hip, qkv_attention2.hip and with it model_kernel.hip)
+// call this one function: equal bits across the routes.
+// The trailing s_nop: gfx940+ needs one wait state between an instruction that writes half a register (SDWA dst_sel) and a
+// reader of that register, and the compiler's hazard pass does not look into an asm block.
+#ifndef BERT_HIP_EXP16
+#define BERT_HIP_EXP16 1
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// the three steps of softmax_p8 on four score PAIRS, separately callable so that a kernel can put MFMAs between them
+// (attention.hip's software-pipelined chunk loop): arguments (8 VALU), exponentials (8 VALU + the wait state), row sum (4 dot2)
+__device__ __forceinline__ u32x4_t softmax_args4(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc, float m) {
+    uint32_t a0, a1, a2, a3;            // (scalar outputs: asm outputs that are elements of a vector come out wrong)
+    asm("v_fma_mixlo_f16 %0, %4, %12, -%13\n\t"
+        "v_fma_mixlo_f16 %1, %6, %12, -%13\n\t"
+        "v_fma_mixlo_f16 %2, %8, %12, -%13\n\t"
+        "v_fma_mixlo_f16 %3, %10, %12, -%13\n\t"
+        "v_fma_mixhi_f16 %0, %5, %12, -%13\n\t"
+        "v_fma_mixhi_f16 %1, %7, %12, -%13\n\t"
+        "v_fma_mixhi_f16 %2, %9, %12, -%13\n\t"
+        "v_fma_mixhi_f16 %3, %11, %12, -%13"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "s"(sc), "v"(m));
+    return u32x4_t{a0, a1, a2, a3};
+}
+__device__ __forceinline__ u32x4_t softmax_exp4(u32x4_t a) {
+    uint32_t p0, p1, p2, p3;
+    asm("v_exp_f16_e32 %0, %4\n\t"
+        "v_exp_f16_e32 %1, %5\n\t"
+        "v_exp_f16_e32 %2, %6\n\t"
+        "v_exp_f16_e32 %3, %7\n\t"
+        "v_exp_f16_sdwa %0, %4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_exp_f16_sdwa %1, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_exp_f16_sdwa %2, %6 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "v_exp_f16_sdwa %3, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1\n\t"
+        "s_nop 0"
+        : "=&v"(p0), "=&v"(p1), "=&v"(p2), "=&v"(p3)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+    return u32x4_t{p0, p1, p2, p3};
+}
+__device__ __forceinline__ void softmax_sum4(u32x4_t p, float &psum) {
+    const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t pe = p[e];       // (a scalar copy: __builtin_bit_cast applied to a vector ELEMENT reads element 0 whatever e is)
+        psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, pe), one, psum, false);
+    }
+}
+__device__ __forceinline__ f16x8_t softmax_p8(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc,
+                                              float m, float &psum) {
+#if BERT_HIP_EXP16
+    const u32x4_t p = softmax_exp4(softmax_args4(s0, s1, s2, s3, s4, s5, s6, s7, sc, m));
+    softmax_sum4(p, psum);
+    return __builtin_bit_cast(f16x8_t, p);
+#else
+    const float s[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+    f16x8_t pf;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sc, -m));
+        psum += pv;
+        pf[e] = (_Float16)pv;
+    }
+    return pf;
+#endif
+}
 // tanh-form GELU of two values, packed f16: x / (1 + 2^(x (c1 + c2 x^2)))
 __device__ __forceinline__ f16x2_t gelu_pk16h(f16x2_t xh) {
     const float c1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f;

@@ -482,16 +482,10 @@ __device__ __forceinline__ void qkv_attention2_body(const Qkv2Args &a, char *sme
             for (int kt = 0; kt < 4; ++kt) {
                 if (FAST || (need & (1u << kt))) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sc, -mx));
-                        s[kt][r] = pv;
-                        psum += pv;
-                    }
-#pragma unroll
                     for (int st = 0; st < 2; ++st) {
-                        f16x8 pf;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = (_Float16)s[kt][8 * st + e];
+                        // (softmax_p8, kernels.h: fp16 argument and exponential like the reference's table, f32 row sum)
+                        const f16x8 pf = softmax_p8(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
+                                                    s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, mx, psum);
                         const int key0 = kt * 32 + 16 * st + 4 * hi;              // keys key0..+3 and key0+8..+11
                         const half_t *vr = VT + l31 * Q2_VT_LD + key0;
                         const f16x4 v0 = *(const f16x4 *)vr, v1 = *(const f16x4 *)(vr + 8);

@@ -1,13 +1,9 @@
 #!/bin/bash
-# tools/variant.sh NAME SRC.hip "-DFLAG=.. ..."  ->  bert.cpp_amd/libbert_NAME.so: libbert.so with ONE translation unit rebuilt
-# with extra flags (A/B runs of a kernel variant in a single gpurun call: BERT_HIP_LIB=bert.cpp_amd/libbert_NAME.so).
+# tools/variant.sh NAME "-DFLAG=.. ..."  ->  bert.cpp_amd/libbert_NAME.so: the whole library rebuilt with extra compiler flags (the
+# Makefile's per-object flags kept), for A/B runs of kernel variants in a single gpurun call: BERT_HIP_LIB=bert.cpp_amd/libbert_NAME.so
 set -e
 cd "$(dirname "$0")/../bert.cpp_amd"
-name=$1; src=$2; flags=$3
-make -s libbert.so >/dev/null
-mkdir -p build_var
-obj=build_var/${name}_$(basename ${src%.hip}).o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -mllvm -structurizecfg-skip-uniform-regions=true $flags -c csrc/$src -o $obj
-objs=$(ls build/*.o | grep -v "build/$(basename ${src%.hip}).o" | grep -v build/test_api.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libbert_${name}.so $objs $obj -ldl -lpthread
+name=$1; flags=$2
+make -s -j16 OBJ=build_var/$name LIB=libbert_$name.so TESTLIB=libbert_${name}_test.so \
+     CXXFLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result -Wno-unused-value $flags" libbert_$name.so libbert_${name}_test.so
 echo "built bert.cpp_amd/libbert_${name}.so"
