@@ -19,6 +19,7 @@
 // Sequences longer than 128 keys stream over 128-key chunks with an online softmax.
 #include "kernels.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace bert_hip {
@@ -95,7 +96,11 @@ struct PipePlan {
 // shape, replay groups of 20 launches: static priority for waves 4-7 (697 against 698-704 us: nothing), the V fragments of a
 // chunk requested in front of its softmax (+0.4 %), the output rescale skipped behind a ballot while no query's maximum grows
 // by more than 2^8 (+2.7 %: the branch costs more than the 32 multiplies).)
-template <int D, int NT, int CH>
+#ifndef BERT_HIP_ATT_PIPE
+#define BERT_HIP_ATT_PIPE 1
+#endif
+// MULTI: sentences of more than one 128-key chunk can occur (the launcher's max_len > 128)
+template <int D, int NT, int CH, bool MULTI = (NT > 256)>
 __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__restrict__ qkv,
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,
                                                              half_t *__restrict__ out) {
@@ -198,10 +203,11 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
         for (int dv = 0; dv < D / 32; ++dv) vbase[dv] = (lds_halfs)Vt + (dv * 32 + l31) * vt_ld + 4 * hi;
         constexpr int K_ROW = D * 2;                   // bytes per K row
 
+#if BERT_HIP_ATT_PIPE
         constexpr int KT = CH / 32;                    // key tiles per step
         static_assert(KT == 4, "the issue plan is written for 128-key chunks");
         constexpr int DV = D / 32, KS = D / 16;
-        constexpr bool PIPE = NT > 256;                // sentences of more than one chunk exist only in the 8-wave form
+        constexpr bool PIPE = MULTI;                   // sentences of more than one chunk
         const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
         typedef const __attribute__((address_space(3))) f16x8 *lds_f16x8;
         typedef const __attribute__((address_space(3))) f16x4 *lds_f16x4;
@@ -254,7 +260,9 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
             float psum = 0.f, mxn = -INFINITY;
-            u32x4_t aa[KT][2], pp[KT][2];
+            sm_arg_t aa[KT][2];
+            sm_exp_t pp[KT][2];
+            f16x8 pk[KT][2];                               // the B fragments of the P·V steps
             f16x8 fr[PIPE_RING];
             auto fragment = [&](const PipeOp op) __attribute__((always_inline)) -> f16x8 {
                 if (op.type == 1) return *(lds_f16x8)(kbase[op.idx] + op.kt * 32 * K_ROW);
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     if (op.type == 1)
                         sn[op.kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[op.idx], op.idx == 0 ? (f32x16)0.f : sn[op.kt], 0, 0, 0);
                     else
-                        o[op.idx % DV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, __builtin_bit_cast(f16x8, pp[op.kt][op.idx / DV]), o[op.idx % DV], 0, 0, 0);
+                        o[op.idx % DV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pk[op.kt][op.idx / DV], o[op.idx % DV], 0, 0, 0);
                 }
                 if (G.piece >= 0) {
                     const int kt = G.piece_kt, st = G.piece >= 2;
@@ -289,7 +297,8 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     } else {
                         if (G.piece == 2 || G.piece == 4) {
                             softmax_sum4(pp[kt][G.piece == 4], psum);
-                            asm volatile("" : "+v"(psum));
+                            pk[kt][G.piece == 4] = softmax_pack(pp[kt][G.piece == 4]);
+                            asm volatile("" : "+v"(psum), "+v"(pk[kt][G.piece == 4]));
                         }
                         if (G.piece == 0 || G.piece == 2) {
                             aa[kt][st] = softmax_args4(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
@@ -329,6 +338,79 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             if (!(kc + 2 * CH < n_steps)) { chunk(std::false_type{}, kc + CH, s2, s); break; }
             chunk(std::true_type{}, kc + CH, s2, s);
         }
+#else      // the straight-line chunk loop of rounds 1-4 (tuning builds: -DBERT_HIP_ATT_PIPE=0)
+        constexpr int KT = CH / 32;                    // key tiles per step
+        const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
+        for (int kc = 0; kc < n_steps; kc += CH) {
+            // ---- S^T chunk: KT key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
+            f32x16 s[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+                for (int kk = 0; kk < D / 16; ++kk) {
+                    const f16x8 kf = *(const __attribute__((address_space(3))) f16x8 *)(kbase[kk] + kt * 32 * K_ROW);
+                    // (the first k-step starts from the constant 0: no zeroing moves)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
+            // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
+            if (kc + CH > n) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        s[kt][r] = key < n ? s[kt][r] : -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit
+            const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
+            // numerators (softmax_p8, kernels.h; the same function in qkv_attention2.hip: equal bits across the kernels)
+            float psum = 0.f;
+            f16x8 pfr[KT][2];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st)
+                    pfr[kt][st] = softmax_p8(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
+                                             s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new, psum);
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dv = 0; dv < D / 32; ++dv)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+            // ---- O^T += V^T * P^T
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const f16x8 pf = pfr[kt][st];
+                    // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
+#pragma unroll
+                    for (int dv = 0; dv < D / 32; ++dv) {
+                        const lds_halfs vr = vbase[dv] + kt * 32 + 16 * st;
+                        const f16x4 v0 = *(const __attribute__((address_space(3))) f16x4 *)vr, v1 = *(const __attribute__((address_space(3))) f16x4 *)(vr + 8);
+                        f16x8 vf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                        o[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dv], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+            for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += CH;
+        }
+#endif
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
         const int q = qb * 32 + l31;
         if (q < n) {
@@ -353,14 +435,18 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
     const int n_pad = (max_len + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const size_t lds = (size_t)n_pad * D * 2 + (size_t)D * (n_pad + VT_PAD) * 2;
     // per device: the opt-in is a per-device attribute; the devices of a context launch from threads of their own
-    static DeviceFlags configured[2];
+    static DeviceFlags configured[3];
     const bool wide = n_pad > 128;
+    // (tuning: BERT_HIP_ATT_WAVES=4 runs long sentences with one wave per SIMD instead of two)
+    static const bool four = [] { const char *e = getenv("BERT_HIP_ATT_WAVES"); return e && atoi(e) == 4; }();
     if (lds > 64 * 1024)
-        configure_once(configured[wide], [&] {                 // (once, for the largest LDS the kernel can be launched with)
-            if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configure_once(configured[wide ? (four ? 2 : 1) : 0], [&] {                 // (once, for the largest LDS the kernel can be launched with)
+            if (wide && four) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            else if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-    if (wide) BERT_LAUNCH((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
+    if (wide && four) BERT_LAUNCH((attention_mfma_kernel<D, 256, 128, true>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
+    else if (wide) BERT_LAUNCH((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
     else BERT_LAUNCH((attention_mfma_kernel<D, 256, 128>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
 }
 

@@ -31,13 +31,14 @@ struct DevBuf {
 // Owns the HBM image of one weight matrix in the layouts kernels.h describes.
 struct GemmWeightStore {
     GemmWeight w;
-    DevBuf w16, w16p, qs, sc, naive16;
+    DevBuf w16, w16p, qs, sc, naive16, w32;
     bool mfma_ok = false;
     // rows: list of (file tensor) stacked along N (one entry, or q|k|v).  All share type and K.
     // want_kperm: also build GemmWeight::w16p (f16 images only); expand_q4: q4_0 / q4_1 tensors become an f16 image at
     // load (default for the engine) instead of the nibble / scale planes of the fused-dequant kernels
+    // want_f32: f32 tensors also keep their own f32 rows (GemmWeight::w32, the f32 route)
     bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm = false,
-               bool expand_q4 = false);
+               bool expand_q4 = false, bool want_f32 = false);
 };
 
 struct LayerWeights {
@@ -86,6 +87,9 @@ public:
 private:
     Engine() = default;
     bool ensure_workspace(int t_pad, int n_sentences, std::string &err);
+    // f32 files in f32 arithmetic (f32_route.hip): the whole pass, one launch per operation
+    int forward_f32(const int32_t *d_tokens, const int32_t *d_cu, int B, int T, int max_len, float *d_out, hipStream_t s, float *d_hidden,
+                    std::string &err);
     template <class F> void timed(const char *name, double flops, hipStream_t s, F &&f);
 
     HParams hp_;
@@ -114,6 +118,8 @@ private:
 
     // options
     bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
+    bool f32_file_ = false;           // every matrix and table of the file is f32: the f32 route can take it
+    bool f32_exact_ = true;           // ... and takes it unless BERT_HIP_F32=f16 / set_option("f32", "f16")
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
 

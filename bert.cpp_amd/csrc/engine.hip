@@ -86,7 +86,7 @@ void row_to_f16(const HostTensor &t, int64_t r, _Float16 *dst) {
 }  // namespace
 
 bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm,
-                            bool expand_q4) {
+                            bool expand_q4, bool want_f32) {
     const int64_t K = rows[0]->ne0;
     const int ftype = rows[0]->type;
     int64_t N = 0;
@@ -144,6 +144,13 @@ bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool wa
         if (!qs.upload(q.data(), q.size(), err) || !sc.upload(s.data(), s.size(), err)) return false;
         w.qs = qs.as<uint4>();
         w.sc = sc.p;
+    }
+    if (want_f32 && ftype == W_F32) {
+        std::vector<uint8_t> all;
+        for (auto *t : rows) all.insert(all.end(), t->data, t->data + t->nbytes);
+        if (all.size() != (size_t)N * K * 4) { err = "f32 tensor size mismatch"; return false; }
+        if (!w32.upload(all.data(), all.size(), err)) return false;
+        w.w32 = w32.as<float>();
     }
     if (!mfma_ok || want_naive) {
         std::vector<_Float16> img((size_t)N * K);
@@ -218,6 +225,8 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
+    // f32 files: f32 arithmetic like the reference's (f32_route.hip) unless BERT_HIP_F32=f16 asks for f16 operands and the fused kernels
+    if (const char *f = getenv("BERT_HIP_F32")) e->f32_exact_ = strcmp(f, "f16") != 0;
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
 
     auto T = [&](const std::string &n) { return mf.find(n); };
@@ -237,6 +246,17 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     ok = ok && upload_f32(e->ln_e_w_, T("embeddings.LayerNorm.weight"), err);
     ok = ok && upload_f32(e->ln_e_b_, T("embeddings.LayerNorm.bias"), err);
     const bool want_naive = e->gemm_naive_;
+    // the f32 route needs every matrix of every layer and the three tables as f32 tensors (a file has one ftype, but check)
+    e->f32_file_ = mf.hp.f16 == 0;
+    for (const char *n : {"embeddings.word_embeddings.weight", "embeddings.token_type_embeddings.weight", "embeddings.position_embeddings.weight"})
+        e->f32_file_ = e->f32_file_ && T(n) && T(n)->type == W_F32;
+    for (int i = 0; e->f32_file_ && i < mf.hp.n_layer; ++i) {
+        const std::string p = "encoder.layer." + std::to_string(i) + ".";
+        for (const char *n : {"attention.self.query.weight", "attention.self.key.weight", "attention.self.value.weight", "attention.output.dense.weight",
+                              "intermediate.dense.weight", "output.dense.weight"})
+            e->f32_file_ = e->f32_file_ && T(p + n) && T(p + n)->type == W_F32;
+    }
+    const bool want_f32 = e->f32_file_;
     // the k-permuted second image of the FFN weights is only read by layer_tail_kernel (H = 256 / 384)
     const bool want_kperm = mf.hp.n_embd % 128 == 0 && mf.hp.n_embd >= 256 && mf.hp.n_embd <= 384;
     for (int i = 0; ok && i < mf.hp.n_layer; ++i) {
@@ -244,16 +264,16 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         auto *L = new LayerWeights;
         e->layers_.push_back(L);
         ok = ok && L->qkv.build({T(p + "attention.self.query.weight"), T(p + "attention.self.key.weight"),
-                                 T(p + "attention.self.value.weight")}, want_naive, err, false, e->q4_expand_);
+                                 T(p + "attention.self.value.weight")}, want_naive, err, false, e->q4_expand_, want_f32);
         ok = ok && concat_upload(L->qkv_b, {T(p + "attention.self.query.bias"), T(p + "attention.self.key.bias"),
                                             T(p + "attention.self.value.bias")}, err);
-        ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err, false, e->q4_expand_);
+        ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err, false, e->q4_expand_, want_f32);
         ok = ok && upload_f32(L->o_b, T(p + "attention.output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_att_w, T(p + "attention.output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_att_b, T(p + "attention.output.LayerNorm.bias"), err);
-        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_);
+        ok = ok && L->ffi.build({T(p + "intermediate.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_, want_f32);
         ok = ok && upload_f32(L->ffi_b, T(p + "intermediate.dense.bias"), err);
-        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_);
+        ok = ok && L->ffo.build({T(p + "output.dense.weight")}, want_naive, err, want_kperm, e->q4_expand_, want_f32);
         ok = ok && upload_f32(L->ffo_b, T(p + "output.dense.bias"), err);
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
@@ -311,6 +331,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
+    else if (key == "f32") f32_exact_ = value != "f16";       // f32 files: "exact" (f32 arithmetic, default) | "f16" (f16 operands, fused kernels)
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
     else if (key == "profile_replay") {
         // "<kernel name>:<K>" (see timed()), "" switches back to an event pair per launch
@@ -322,8 +343,9 @@ void Engine::set_option(const std::string &key, const std::string &value) {
 
 bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
-    return x_.ensure(tp * H * 2, err) && qkv_.ensure(tp * 3 * H * 2, err) && ctx_.ensure(tp * H * 2, err) &&
-           y_.ensure(tp * H * 2, err) && ff_.ensure(tp * I * 2, err) && v32_.ensure((size_t)128 * H * 4, err) &&
+    const size_t es = f32_file_ ? 4 : 2;                      // (f32 files: the f32 route's activations are f32)
+    return x_.ensure(tp * H * es, err) && qkv_.ensure(tp * 3 * H * es, err) && ctx_.ensure(tp * H * es, err) &&
+           y_.ensure(tp * H * es, err) && ff_.ensure(tp * I * es, err) && v32_.ensure((size_t)128 * H * 4, err) &&
            d_out_.ensure((size_t)n_sentences * H * 4, err) &&
            windows_.ensure((size_t)n_sentences * sizeof(int2), err);
 }
@@ -415,6 +437,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     replay_done_ = false;
     // one forward pass at a time on the shared workspace: wait (on the caller's stream) for the previous pass
     HIP_OK(hipStreamWaitEvent(s, busy_, 0), err, -1);
+    if (f32_file_ && f32_exact_) return forward_f32(d_tokens, d_cu, B, T, max_len, d_out, s, d_hidden, err);
     half_t *x = x_.as<half_t>(), *qkv = qkv_.as<half_t>(), *ctx = ctx_.as<half_t>(), *y = y_.as<half_t>(),
            *ff = ff_.as<half_t>();
     const double Td = (double)T;
@@ -561,6 +584,44 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     }
     // (the one-launch kernel's workgroups pool their sentences themselves)
     if (!one_launch) timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_pool_normalize(x, d_cu, B, H, max_len, status_.as<int>(), d_out, s); });
+    (void)I;
+    HIP_OK(hipGetLastError(), err, -1);
+    HIP_OK(hipEventRecord(busy_, s), err, -1);
+    return 0;
+}
+
+// f32 files at the reference's precision (f32_route.hip; reference bert.cpp:784-913 with GGML_TYPE_F32 tensors): the same
+// sequence of operations as the tiled family, every one in f32.  Called from eval_packed_device behind its workspace sizing
+// and its wait for the previous pass.
+int Engine::forward_f32(const int32_t *d_tokens, const int32_t *d_cu, int B, int T, int max_len, float *d_out, hipStream_t s, float *d_hidden,
+                        std::string &err) {
+    const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
+    float *x = x_.as<float>(), *qkv = qkv_.as<float>(), *ctx = ctx_.as<float>(), *y = y_.as<float>(), *ff = ff_.as<float>();
+    const double Td = (double)T;
+    auto gemm = [&](const char *name, GemmWeightStore &W, const float *A, const float *bias, const float *resid, float *C, int epi) {
+        if (profiling_ && replay_name_.empty()) families_["family:gemm_f32"] += 1;
+        timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] { launch_f32_gemm(A, W.w.w32, bias, resid, C, T, W.w.N, W.w.K, epi, s); });
+    };
+    auto tap = [&](int idx) {
+        if (d_hidden) (void)hipMemcpyAsync(d_hidden + (size_t)idx * T * H, x, (size_t)T * H * 4, hipMemcpyDeviceToDevice, s);
+    };
+    timed("embed_ln", 0.0, s, [&] {
+        launch_f32_embed_ln(word_emb_.as<float>(), type_emb_.as<float>(), pos_emb_.as<float>(), ln_e_w_.as<float>(), ln_e_b_.as<float>(), d_tokens,
+                            d_cu, B, T, H, hp_.n_vocab, x, s);
+    });
+    tap(0);
+    for (int il = 0; il < hp_.n_layer; ++il) {
+        LayerWeights &L = *layers_[il];
+        gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
+        timed("attention", 4.0 * Td * max_len * H, s, [&] { launch_f32_attention(qkv, d_cu, B, nh, dh, max_len, ctx, s); });
+        gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID);
+        timed("layernorm", 0.0, s, [&] { launch_f32_layernorm(y, L.ln_att_w.as<float>(), L.ln_att_b.as<float>(), T, H, s); });
+        gemm("gemm_ffn_up", L.ffi, y, L.ffi_b.as<float>(), nullptr, ff, EPI_BIAS_GELU);
+        gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID);
+        timed("layernorm", 0.0, s, [&] { launch_f32_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+        tap(il + 1);
+    }
+    timed("pool_normalize", 2.0 * Td * H, s, [&] { launch_f32_pool_normalize(x, d_cu, B, H, max_len, status_.as<int>(), d_out, s); });
     (void)I;
     HIP_OK(hipGetLastError(), err, -1);
     HIP_OK(hipEventRecord(busy_, s), err, -1);

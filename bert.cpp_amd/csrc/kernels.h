@@ -41,9 +41,15 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 #define BERT_HIP_EXP16 1
 #endif
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
 // the three steps of softmax_p8 on four score PAIRS, separately callable so that a kernel can put MFMAs between them
-// (attention.hip's software-pipelined chunk loop): arguments (8 VALU), exponentials (8 VALU + the wait state), row sum (4 dot2)
-__device__ __forceinline__ u32x4_t softmax_args4(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc, float m) {
+// (attention.hip's software-pipelined chunk loop): arguments (8 VALU), exponentials (8 VALU + the wait state), row sum (4 dot2);
+// softmax_pack: the B fragment of the P·V MFMA step (the exponentials themselves in the fp16 form).
+// -DBERT_HIP_EXP16=0 (tuning builds): the f32 form of rounds 1-4 — fma, v_exp_f32, add, v_cvt_pk_f16_f32.
+#if BERT_HIP_EXP16
+typedef u32x4_t sm_arg_t;
+typedef u32x4_t sm_exp_t;
+__device__ __forceinline__ sm_arg_t softmax_args4(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc, float m) {
     uint32_t a0, a1, a2, a3;            // (scalar outputs: asm outputs that are elements of a vector come out wrong)
     asm("v_fma_mixlo_f16 %0, %4, %12, -%13\n\t"
         "v_fma_mixlo_f16 %1, %6, %12, -%13\n\t"
@@ -57,7 +63,7 @@ __device__ __forceinline__ u32x4_t softmax_args4(float s0, float s1, float s2, f
         : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(s4), "v"(s5), "v"(s6), "v"(s7), "s"(sc), "v"(m));
     return u32x4_t{a0, a1, a2, a3};
 }
-__device__ __forceinline__ u32x4_t softmax_exp4(u32x4_t a) {
+__device__ __forceinline__ sm_exp_t softmax_exp4(sm_arg_t a) {
     uint32_t p0, p1, p2, p3;
     asm("v_exp_f16_e32 %0, %4\n\t"
         "v_exp_f16_e32 %1, %5\n\t"
@@ -72,7 +78,7 @@ __device__ __forceinline__ u32x4_t softmax_exp4(u32x4_t a) {
         : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
     return u32x4_t{p0, p1, p2, p3};
 }
-__device__ __forceinline__ void softmax_sum4(u32x4_t p, float &psum) {
+__device__ __forceinline__ void softmax_sum4(sm_exp_t p, float &psum) {
     const f16x2_t one = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -80,23 +86,39 @@ __device__ __forceinline__ void softmax_sum4(u32x4_t p, float &psum) {
         psum = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2_t, pe), one, psum, false);
     }
 }
-__device__ __forceinline__ f16x8_t softmax_p8(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc,
-                                              float m, float &psum) {
-#if BERT_HIP_EXP16
-    const u32x4_t p = softmax_exp4(softmax_args4(s0, s1, s2, s3, s4, s5, s6, s7, sc, m));
-    softmax_sum4(p, psum);
-    return __builtin_bit_cast(f16x8_t, p);
+__device__ __forceinline__ f16x8_t softmax_pack(sm_exp_t p) { return __builtin_bit_cast(f16x8_t, p); }
 #else
+typedef f32x8_t sm_arg_t;
+typedef f32x8_t sm_exp_t;
+__device__ __forceinline__ sm_arg_t softmax_args4(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc, float m) {
     const float s[8] = {s0, s1, s2, s3, s4, s5, s6, s7};
+    f32x8_t a;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = __builtin_fmaf(s[e], sc, -m);
+    return a;
+}
+__device__ __forceinline__ sm_exp_t softmax_exp4(sm_arg_t a) {
+    f32x8_t p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(a[e]);
+    return p;
+}
+__device__ __forceinline__ void softmax_sum4(sm_exp_t p, float &psum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) psum += p[e];
+}
+__device__ __forceinline__ f16x8_t softmax_pack(sm_exp_t p) {
     f16x8_t pf;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], sc, -m));
-        psum += pv;
-        pf[e] = (_Float16)pv;
-    }
+    for (int e = 0; e < 8; ++e) pf[e] = (_Float16)p[e];
     return pf;
+}
 #endif
+__device__ __forceinline__ f16x8_t softmax_p8(float s0, float s1, float s2, float s3, float s4, float s5, float s6, float s7, float sc,
+                                              float m, float &psum) {
+    const sm_exp_t p = softmax_exp4(softmax_args4(s0, s1, s2, s3, s4, s5, s6, s7, sc, m));
+    softmax_sum4(p, psum);
+    return softmax_pack(p);
 }
 // tanh-form GELU of two values, packed f16: x / (1 + 2^(x (c1 + c2 x^2)))
 __device__ __forceinline__ f16x2_t gelu_pk16h(f16x2_t xh) {
@@ -146,6 +168,8 @@ struct GemmWeight {
     // optional second f16 image whose k order inside every group of 16 is [0-3, 8-11, 4-7, 12-15]: a 16-byte half
     // of a group then holds the k's one lane of an MFMA accumulator column owns (layer_tail.hip)
     const half_t *w16p = nullptr;
+    // f32 files (ftype 0) with the f32 route (f32_route.hip): the file's own f32 rows, [N][K] row-major
+    const float *w32 = nullptr;
 };
 
 // C[t][n] = epi( sum_k A[t][k] * W[n][k] + bias[n] (+ resid[t][n]) ), t < M_pad (multiple of 128)
@@ -268,6 +292,18 @@ inline thread_local const LaunchTiming *tl_launch_timing = nullptr;
                                   ::bert_hip::tl_launch_timing->stop, 0, __VA_ARGS__);                                        \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                               \
     } while (0)
+
+// The f32 route (f32_route.hip): the forward pass of f32 model files in f32 arithmetic — f32 activations, mat-muls on
+// v_mfma_f32_32x32x2_f32 (any M, N, K; C = epi(A W^T + bias (+ resid))), f32 softmax / GELU / LayerNorm / pooling.
+void launch_f32_embed_ln(const float *word, const float *type, const float *pos, const float *gamma, const float *beta, const int32_t *tokens,
+                         const int32_t *cu_seqlens, int n_sentences, int T, int H, int n_vocab, float *out, hipStream_t stream);
+void launch_f32_gemm(const float *A, const float *W, const float *bias, const float *resid, float *C, int M, int N, int K, int epilogue,
+                     hipStream_t stream);
+void launch_f32_attention(const float *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head, int max_len, float *out,
+                          hipStream_t stream);
+void launch_f32_layernorm(float *x, const float *gamma, const float *beta, int T, int H, hipStream_t stream);
+void launch_f32_pool_normalize(const float *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status, float *out,
+                               hipStream_t stream);
 
 // f16 [rows][cols] -> f32 (hidden-state tap)
 void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream);

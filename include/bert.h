@@ -22,9 +22,10 @@
  *   - f16 files: f16 operands, f32 accumulation — the reference's own class for these files;
  *   - q4_0 / q4_1 files: blocks dequantised to f16 ((q - 8) d, q d + m), f16 activations, f32 accumulation (the reference
  *     also quantises the activations to 8 bits per 32-block: this engine is the closer one to exact arithmetic);
- *   - f32 files: the weight matrices are ROUNDED TO F16 ONCE AT LOAD and the activations are f16, f32 accumulation — narrower
- *     than the reference's pure-f32 mat-mul for this file type (bert.cpp:825 with GGML_TYPE_F32).  Embedding tables, biases
- *     and LayerNorm parameters stay f32.  Measured on synthetic weights: cosine >= 1 - 1e-4 against the f32 oracle (tests).
+ *   - f32 files: f32 weights, f32 activations, f32 accumulation on the matrix cores' f32 form (v_mfma_f32_32x32x2_f32), f32
+ *     softmax / GELU / LayerNorm — the reference's pure-f32 mat-mul for this file type (bert.cpp:825 with GGML_TYPE_F32);
+ *     max-abs 2e-5 per embedding component against f32 arithmetic on the CPU (tests).  BERT_HIP_F32=f16 (bert_hip.h) asks for
+ *     the faster f16-operand kernels instead (weights rounded to f16 once at load; cosine >= 1 - 1e-4).
  */
 #ifndef BERT_H
 #define BERT_H

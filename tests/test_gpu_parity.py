@@ -529,6 +529,60 @@ def test_eval_matches_oracle_baseline_models(make_model, dims, ftype, n, lens):
     assert min(plain) >= TIGHT_COS_PLAIN, (dims, ftype, plain)
 
 
+@pytest.mark.parametrize("dims,lens", [
+    ("tiny", LENS), ("tiny-d64", LENS), ("tiny-d16", LENS), ("tiny-h128", LENS),
+    ("minilm-l6", [128, 20, 1, 77]), ("bert-base", [300, 17]),
+])
+def test_f32_files_run_in_f32_arithmetic(make_model, dims, lens):
+    """f32 model files (ftype 0) take ggml's f32 mat-mul in the reference (bert.cpp:825 with GGML_TYPE_F32 tensors, typed at
+    :407-429): the engine's f32 route (f32_route.hip: f32 activations, v_mfma_f32_32x32x2_f32, f32 softmax / GELU / LayerNorm)
+    must reproduce the oracle's plain f32 arithmetic to max-abs 2e-5 per embedding component — an f16-operand pass is 50x
+    off that.  The route is what runs by default (kernel family asserted); "f32" = "f16" selects f16 operands and the fused
+    kernels, which stay within the cosine tolerance of every other file type."""
+    path, hp = make_model(dims, "f32", 1)
+    m = pybert.BertModel(path)
+    o = orc.Oracle(path)
+    rng = np.random.default_rng(11)
+    sents = [rng.integers(0, hp.n_vocab, size=min(n, hp.n_max_tokens)).astype(np.int32) for n in lens]
+    m.profile(True)
+    got = m.eval_batch(sents)
+    rep = m.profile_report(families=True)
+    m.profile(False)
+    assert rep.get("family:gemm_f32", {}).get("launches") == 4 * hp.n_layer and not any(k.startswith("family:gemm") and k != "family:gemm_f32" for k in rep), rep
+    worst = 0.0
+    for s, g in zip(sents, got):
+        plain = o.eval(s, orc.MODE_PLAIN)
+        worst = max(worst, float(np.abs(g - plain).max()))
+        assert abs(np.linalg.norm(g) - 1) < 1e-5
+        assert cosine(g, o.eval(s, orc.MODE_GGML)) >= 1 - 1e-4          # (ggml mode: fp16 exp / GELU tables on f32 mat-muls)
+    assert worst <= 2e-5, (dims, worst)
+    # per-sentence results do not depend on the batch or the entry point
+    assert np.array_equal(np.stack([m.eval(s) for s in sents]), got)
+    # the f16-operand route on the same file
+    m.set_option("f32", "f16")
+    m.profile(True)
+    fast = m.eval_batch(sents)
+    rep = m.profile_report(families=True)
+    m.profile(False)
+    assert "family:gemm_f32" not in rep, rep
+    assert min(cosine(a, b) for a, b in zip(fast, got)) >= 1 - 1e-4
+    m.set_option("f32", "exact")
+    assert np.array_equal(m.eval_batch(sents), got)
+
+
+def test_f32_route_hidden_states(make_model):
+    """Layer-by-layer tap of the f32 route against the oracle's plain mode (bert.cpp:806-901)."""
+    path, hp = make_model("tiny", "f32", 2)
+    m = pybert.BertModel(path)
+    o = orc.Oracle(path)
+    s = np.random.default_rng(9).integers(0, hp.n_vocab, size=40).astype(np.int32)
+    emb, hid = m.eval_hidden(s)
+    want_emb, want_hid = o.eval(s, orc.MODE_PLAIN, want_hidden=True)
+    for layer in range(hp.n_layer + 1):
+        assert np.abs(hid[layer] - want_hid[layer]).max() < 2e-4 * (1 + layer), layer
+    assert np.abs(emb - want_emb).max() <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------------
 # API semantics (SURVEY.md §8b)
 # ------------------------------------------------------------------------------------------------
