@@ -18,7 +18,9 @@
 // the V^T fragment is gathered with the same permutation (two 8-byte LDS reads).
 // Sequences longer than 128 keys stream over 128-key chunks with an online softmax.
 #include "kernels.h"
+#include "tile_stream.h"      // (the timeline stamps of the tuning builds)
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -28,6 +30,22 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// In-kernel phase clock of the tuning builds (-DBERT_HIP_TIMELINE): wave 0 and wave 4 of a workgroup (the two waves of one SIMD)
+// add up, over all their items and chunks, the shader cycles between phase boundaries: staging (an item's start to behind its
+// barrier), S^T (issue to RESULTS: the mark names the accumulators, so the matrix pipe has delivered them), softmax (to the
+// last P fragment and the rescaled output accumulators), P·V (to the output accumulators), store.  A mark is two empty
+// volatile asm statements around s_memtime that name the values the next phase starts from: nothing of the next phase can
+// be scheduled in front of it, nothing of the previous one behind it.  launch_att prints the sums of a few workgroups.
+#ifdef BERT_HIP_TIMELINE
+#define ATT_TL(...) __VA_ARGS__
+__device__ __forceinline__ long long att_clock() {
+    long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#else
+#define ATT_TL(...)
+#endif
 constexpr int ATT_CHUNK = 128;      // keys per online-softmax step (4 S^T tiles of 32)
 constexpr int VT_PAD = 4;           // halfs of padding per V^T row: 8-byte skew -> conflict-free ds_read_b64
 
@@ -38,54 +56,15 @@ __device__ __forceinline__ int k_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-// ---- the chunk loop's issue plan (compile time) --------------------------------------------------------------------
-// One wave works through a 128-key chunk as: S^T (KT * D/16 MFMAs), softmax (VALU), O^T += V^T P^T (KT * 2 * D/32 MFMAs).
-// Issued in that order — rounds 1-4 — the matrix pipe idles through the softmax and the VALU through both mat-muls of the
-// wave, two waves per SIMD overlap only where they happen to be out of step, and every MFMA waits for a fragment requested
-// one MFMA earlier (512 x 512 tokens, d_head 64: MFMA busy 27 %, 743 us; profiles/r4_pmc.txt).  Round 5 software-pipelines
-// the loop INSIDE the wave: while the softmax of chunk i runs, the wave issues the S^T MFMAs of chunk i + 1 (into a second
-// set of score registers) and the P·V MFMAs of the key tile whose numerators were finished one step earlier.  The body is a
-// list of GROUPS, each = at most one MFMA + one piece of VALU work, in the program order below (sched_barrier between
-// groups: the machine scheduler may not regroup them); an MFMA's LDS fragment is requested PIPE_RING - 1 MFMAs ahead.
-//   key tile kt = 0..3:  MFMAs  S(i+1)[kt] k-step 0, P·V(kt-1) step 0, S(i+1)[kt] k-step 1, P·V(kt-1) step 1, ...
-//                        VALU   arguments(kt, keys 0-15) | exponentials | row sum + arguments(keys 16-31) | exponentials | row sum
-//   tail:                MFMAs  P·V(3) ...               VALU   in-lane maximum of S(i+1), one tile per group
-// The arithmetic per score is unchanged (softmax_args4 / _exp4 / _sum4 are softmax_p8's three steps, kernels.h; the row sum runs
-// over the pairs in the same order): the same bits as the straight-line form and as qkv_attention2.hip.
-struct PipeOp { int type, kt, idx; };          // type 1: S tile kt of the NEXT chunk, k-step idx; 2: P·V of key tile kt, step idx = st * DV + dv
-struct PipeGroup { int op, piece_kt, piece; }; // op: index into ops, or -1; piece 0..4 of key tile piece_kt (piece_kt 4: maximum of next tile `piece`), or -1
-constexpr int PIPE_RING = 4;
-template <int D, bool NEXT>
-struct PipePlan {
-    static constexpr int KS = D / 16, PVN = 2 * (D / 32);
-    PipeOp ops[64];
-    PipeGroup g[64];
-    int n_ops, n;
-    constexpr PipePlan() : ops{}, g{}, n_ops(0), n(0) {
-        for (int kt = 0; kt <= 4; ++kt) {
-            PipeOp list[16] = {};
-            int nl = 0;
-            const int ns = (NEXT && kt < 4) ? KS : 0, np = kt >= 1 ? PVN : 0;
-            for (int i = 0; i < (ns > np ? ns : np); ++i) {
-                if (i < ns) list[nl++] = PipeOp{1, kt, i};
-                if (i < np) list[nl++] = PipeOp{2, kt - 1, i};
-            }
-            const int npiece = kt < 4 ? 5 : (NEXT ? 4 : 0);
-            const int ng = nl > npiece ? nl : npiece;
-            int placed = 0;
-            for (int i = 0; i < ng; ++i) {
-                PipeGroup x{-1, kt, i < npiece ? i : -1};
-                // the MFMAs of this key tile spread evenly over its groups
-                if (placed < nl && i * nl >= placed * ng) {
-                    x.op = n_ops;
-                    ops[n_ops++] = list[placed++];
-                }
-                g[n++] = x;
-            }
-        }
-    }
-};
-
+// ---- measured and removed in round 5 (commit 37a896e holds the source; numbers in profiles/r5_experiments.txt) ----------------
+// A chunk loop SOFTWARE-PIPELINED inside the wave: while the softmax of chunk i runs, the wave issues the S^T MFMAs of chunk
+// i + 1 into a second set of score registers and the P·V MFMAs of the key tile whose numerators were finished one step
+// earlier — groups of one MFMA + one piece of VALU work in a fixed program order (sched_barrier between groups, results
+// pinned by empty volatile asm), every LDS fragment requested three MFMAs ahead, the score sets alternating (no copies).
+// Same bits (395 tests).  512 x 512 tokens, d_head 64, per 12 launches: 9.79 ms against 8.68 ms for the straight loop below
+// with eight waves, 10.46 with four (one per SIMD).  Why (tools/ubench/valu_cost.hip, profiles/r5_valu_cost.txt): beside MFMAs
+// a v_exp_f32 still costs a wave 7.9 cycles (two waves per SIMD) and the loop needs 64 per chunk and lane; the phases of two
+// waves that are out of step already overlap; what the straight loop loses is elsewhere (phase clock).
 // NT threads: 256 (4 waves), or 512 for long sentences (their K / V^T fill most of the CU's LDS, so one workgroup is all
 // a CU holds: 8 waves = two per SIMD let one wave's softmax run under the other's MFMAs).  CH = keys per online-softmax
 // step.  (Sixteen waves with 64-key steps — four per SIMD within 128 registers — were measured at 512 x 512 tokens: 3 %
@@ -96,31 +75,89 @@ struct PipePlan {
 // shape, replay groups of 20 launches: static priority for waves 4-7 (697 against 698-704 us: nothing), the V fragments of a
 // chunk requested in front of its softmax (+0.4 %), the output rescale skipped behind a ballot while no query's maximum grows
 // by more than 2^8 (+2.7 %: the branch costs more than the 32 multiplies).)
-#ifndef BERT_HIP_ATT_PIPE
-#define BERT_HIP_ATT_PIPE 1
-#endif
-// MULTI: sentences of more than one 128-key chunk can occur (the launcher's max_len > 128)
+// MULTI: sentences of more than one 128-key chunk can occur (the launcher's max_len > 128).  Such a workgroup fills most of its CU's
+// LDS and is alone on it, so nothing hides its staging — global loads of 128 KiB, the transposing LDS stores, the barrier: 19 k of
+// a workgroup's 55 k cycles at 512 tokens (timeline of round 5, profiles/r5_attention_timeline.txt).  The MULTI form is
+// therefore PERSISTENT: a workgroup walks the (sentence, head) items v = blockIdx.x, + gridDim.x, ... and requests the NEXT
+// item's K / V rows into registers (64 per thread) before it computes the current one; at the next turn they only have to be
+// written to LDS.  n_items: the number of items (the grid of the non-persistent form).
 template <int D, int NT, int CH, bool MULTI = (NT > 256)>
 __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__restrict__ qkv,
                                                              const int32_t *__restrict__ cu_seqlens, int n_head,
-                                                             half_t *__restrict__ out) {
+                                                             half_t *__restrict__ out, int n_items) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // XCD-contiguous logical order (see gemm.hip xcd_remap): the heads of one sentence share the
-    // 128-byte lines of its Q|K|V rows, so they should hit the same XCD's L2.
-    const int nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7, xcd = blockIdx.x & 7;
-    const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-    const int b = lb / n_head, h = lb % n_head;
-    const int tok0 = cu_seqlens[b], n = cu_seqlens[b + 1] - tok0;
-    if (n <= 0) return;
+    constexpr bool PERSIST = MULTI;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
     const int H = n_head * D, ld = 3 * H;
+    // XCD-contiguous logical order (see gemm.hip xcd_remap): the heads of one sentence share the
+    // 128-byte lines of its Q|K|V rows, so they should hit the same XCD's L2.  (Persistent: gridDim.x is a multiple of 8, a
+    // workgroup's items stay on its XCD.)
+    struct Item { int h, tok0, n; };
+    auto item_of = [&](int v) -> Item {
+        const int q8 = n_items >> 3, r8 = n_items & 7, xcd = v & 7;
+        const int lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
+        const int b = lb / n_head, t0 = cu_seqlens[b];
+        return Item{lb % n_head, t0, cu_seqlens[b + 1] - t0};
+    };
+    // timeline (tuning builds): wave 0 stamps 0.., wave 4 — the other wave of its SIMD — 64..: 0 start, 1 staging done, 2 behind the
+    // barrier, then per (query block pass, chunk) four stamps: chunk top, S^T issued, softmax done, P·V issued; last: rows stored
+    ATT_TL(long long tl_sum[6] = {0, 0, 0, 0, 0, 0}; long long tl_t = att_clock(); const long long tl_t00 = tl_t; int tl_chunks = 0;)
+#define ATT_MARK(k) ATT_TL({ const long long tl_now = att_clock(); tl_sum[k] += tl_now - tl_t; tl_t = tl_now; })
+
+    // ---- K (swizzled rows) and V^T (transposed) of a head in LDS, the padding zeroed.  A thread takes 16-byte chunk c of the
+    // row PAIR (2 rp, 2 rp + 1): V^T then goes out as 4-byte stores (two keys of one feature), half as many as row by row.
+    // EVERY load of a thread is in flight before its first LDS store (one HBM round trip per loop iteration — the rolled
+    // form — was most of the kernel's time at 512 tokens).
+    constexpr int CPR = D / 8;                         // 16-byte chunks per row
+    constexpr int UNR = 4;                             // row pairs in flight per thread: 16 loads of 16 bytes
+    uint4 kv[UNR][2], vv[UNR][2];
+    auto request = [&](const Item &it, int base) __attribute__((always_inline)) {
+        const int total = ((it.n + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK / 2) * CPR;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                kv[u][w] = uint4{0, 0, 0, 0}; vv[u][w] = uint4{0, 0, 0, 0};
+                const int row = 2 * rp + w;
+                if (idx < total && row < it.n) {
+                    const half_t *src = qkv + (size_t)(it.tok0 + row) * ld + it.h * D + c * 8;
+                    kv[u][w] = *(const uint4 *)(src + H);
+                    vv[u][w] = *(const uint4 *)(src + 2 * H);
+                }
+            }
+        }
+    };
+    auto deposit = [&](char *Ks, half_t *Vt, int vt_ld, int total, int base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
+            if (idx < total) {
+                *(uint4 *)(Ks + k_off<D>(2 * rp, c)) = kv[u][0];
+                *(uint4 *)(Ks + k_off<D>(2 * rp + 1, c)) = kv[u][1];
+                const f16x8 a = __builtin_bit_cast(f16x8, vv[u][0]), b = __builtin_bit_cast(f16x8, vv[u][1]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+                    *(f16x2v *)(Vt + (c * 8 + e) * vt_ld + 2 * rp) = f16x2v{a[e], b[e]};
+                }
+            }
+        }
+    };
+
+    int v = blockIdx.x;
+    Item cur = item_of(v);
+    if (PERSIST && cur.n > 0) request(cur, tid);
+    for (bool first = true;; first = false) {
+    const int h = cur.h, tok0 = cur.tok0, n = cur.n;
+    Item nxt{0, 0, 0};
+    if (n > 0) {
+    ATT_MARK(5)                                        // (between items: the walk, the next item's requests)
     const int n_pad = (n + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const int vt_ld = n_pad + VT_PAD;                 // halfs per V^T row
     char *Ks = smem;                                   // [n_pad][D] halfs, swizzled
     half_t *Vt = (half_t *)(smem + (size_t)n_pad * D * 2);   // [D][vt_ld]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hi = lane >> 5;
-
     const int n_qblocks = (n + 31) / 32;
     // Q fragments of this wave's first query block are requested before the K/V staging loads so that
     // both HBM round trips overlap (B operand: lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +8]).
@@ -131,58 +168,30 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
 #pragma unroll
         for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
     }
-
-    // ---- stage K (swizzled rows) and V^T (transposed) of this head; zero the padding.  A thread takes 16-byte chunk c of the
-    // row PAIR (2 rp, 2 rp + 1): V^T then goes out as 4-byte stores (two keys of one feature), half as many as row by row.
-    // EVERY load of a thread is in flight before its first LDS store (a long sentence's workgroup is alone on its CU: one
-    // HBM round trip per loop iteration — the rolled form — was most of the kernel's time at 512 tokens).
-    constexpr int CPR = D / 8;                         // 16-byte chunks per row
     {
         const int total = (n_pad / 2) * CPR;
-        constexpr int UNR = 4;                         // row pairs in flight per thread: 16 loads of 16 bytes
-        for (int base = tid; base < total; base += NT * UNR) {
-            uint4 kv[UNR][2], vv[UNR][2];
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    kv[u][w] = uint4{0, 0, 0, 0}; vv[u][w] = uint4{0, 0, 0, 0};
-                    const int row = 2 * rp + w;
-                    if (idx < total && row < n) {
-                        const half_t *src = qkv + (size_t)(tok0 + row) * ld + h * D + c * 8;
-                        kv[u][w] = *(const uint4 *)(src + H);
-                        vv[u][w] = *(const uint4 *)(src + 2 * H);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int idx = base + u * NT, rp = idx / CPR, c = idx % CPR;
-                if (idx < total) {
-                    *(uint4 *)(Ks + k_off<D>(2 * rp, c)) = kv[u][0];
-                    *(uint4 *)(Ks + k_off<D>(2 * rp + 1, c)) = kv[u][1];
-                    const f16x8 a = __builtin_bit_cast(f16x8, vv[u][0]), b = __builtin_bit_cast(f16x8, vv[u][1]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
-                        *(f16x2v *)(Vt + (c * 8 + e) * vt_ld + 2 * rp) = f16x2v{a[e], b[e]};
-                    }
-                }
-            }
+        if (!PERSIST) request(cur, tid);
+        if (PERSIST && !first) __syncthreads();            // the previous item's fragment reads are done
+        deposit(Ks, Vt, vt_ld, total, tid);
+        for (int base = tid + NT * UNR; base < total; base += NT * UNR) {      // (heads beyond 32 K elements: not prefetched)
+            request(cur, base);
+            deposit(Ks, Vt, vt_ld, total, base);
         }
     }
     __syncthreads();
+    ATT_MARK(0)
+    if (PERSIST && v + (int)gridDim.x < n_items) {
+        nxt = item_of(v + (int)gridDim.x);
+        if (nxt.n > 0) request(nxt, tid);              // in flight under this item's mat-muls
+    }
 
     const float sc = 1.44269504088896340736f / __builtin_sqrtf((float)D);   // log2(e) / sqrt(d)
+    // One pass = one query block of this wave.  The next query block's Q fragments are requested into the SAME registers behind the
+    // last chunk's S^T MFMAs of the pass before (they are dead there): the round trip runs under that chunk's softmax and P·V.
+    // (Requested a whole pass ahead into registers of their own — and the next item's K / V rows only in the last pass, the pass
+    // body instantiated twice so that the two prefetches never hold registers together — the 8-wave form still spilled 43
+    // registers and ran 11.4 against 8.4 ms per 12 launches at 512 tokens; the 4-wave form of short sentences lost its third wave.)
     for (int qb = wave; qb < n_qblocks; qb += NT / 64) {
-        if (qb != wave) {                              // later blocks (n > 128): fetch their Q fragments now
-            const int qrow = min(qb * 32 + l31, n - 1);
-            const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
-#pragma unroll
-            for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
-        }
-
         f32x16 o[D / 32];
 #pragma unroll
         for (int dv = 0; dv < D / 32; ++dv)
@@ -203,147 +212,14 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
         for (int dv = 0; dv < D / 32; ++dv) vbase[dv] = (lds_halfs)Vt + (dv * 32 + l31) * vt_ld + 4 * hi;
         constexpr int K_ROW = D * 2;                   // bytes per K row
 
-#if BERT_HIP_ATT_PIPE
-        constexpr int KT = CH / 32;                    // key tiles per step
-        static_assert(KT == 4, "the issue plan is written for 128-key chunks");
-        constexpr int DV = D / 32, KS = D / 16;
-        constexpr bool PIPE = MULTI;                   // sentences of more than one chunk
-        const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
-        typedef const __attribute__((address_space(3))) f16x8 *lds_f16x8;
-        typedef const __attribute__((address_space(3))) f16x4 *lds_f16x4;
-
-        // ---- prologue: S^T of the first chunk; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
-        f32x16 s[KT];
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const f16x8 kf = *(lds_f16x8)(kbase[kk] + kt * 32 * K_ROW);
-                // (the first k-step starts from the constant 0: no zeroing moves)
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
-            }
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) kbase[kk] += CH * K_ROW;        // kbase: the NEXT chunk's K rows
-        // the ragged tail of a chunk (only a sentence's last chunk can have one) -> -inf; in-lane maximum of the raw scores
-        auto mask_tail = [&](f32x16 (&t)[KT], int kc) __attribute__((always_inline)) {
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kc + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    t[kt][r] = key < n ? t[kt][r] : -INFINITY;
-                }
-        };
-        auto tile_max = [&](const f32x16 &t, float mx) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(t[r], t[r + 1]), mx);   // v_max3_f32
-            return mx;
-        };
-        // (the volatile asm keeps the rare path a real branch: if-converted, its 64 compares and selects run in every chunk)
-        if (CH > n) { asm volatile("; ragged first chunk" ::: "memory"); mask_tail(s, 0); }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) mx = tile_max(s[kt], mx);
-
-        // ---- one chunk: softmax of s, O^T += V^T P^T; NEXT: S^T of the following chunk computed underneath (-> s, mx)
-        // (s: the chunk's scores; sn receives the following chunk's — the loop below alternates two register sets, a copy
-        // sn -> s at the end of every chunk would be 32 v_mov_b64 behind an MFMA-result wait)
-        auto chunk = [&](auto next_tag, int kc, f32x16 (&s)[KT], f32x16 (&sn)[KT]) __attribute__((always_inline)) {
-            constexpr bool NEXT = decltype(next_tag)::value;
-            static constexpr PipePlan<D, NEXT> plan{};
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit
-            const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
-#pragma unroll
-            for (int dv = 0; dv < DV; ++dv)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
-            float psum = 0.f, mxn = -INFINITY;
-            sm_arg_t aa[KT][2];
-            sm_exp_t pp[KT][2];
-            f16x8 pk[KT][2];                               // the B fragments of the P·V steps
-            f16x8 fr[PIPE_RING];
-            auto fragment = [&](const PipeOp op) __attribute__((always_inline)) -> f16x8 {
-                if (op.type == 1) return *(lds_f16x8)(kbase[op.idx] + op.kt * 32 * K_ROW);
-                // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
-                const lds_halfs vr = vbase[op.idx % DV] + op.kt * 32 + 16 * (op.idx / DV);
-                const f16x4 v0 = *(lds_f16x4)vr, v1 = *(lds_f16x4)(vr + 8);
-                return f16x8{v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            };
-#pragma unroll
-            for (int j = 0; j < PIPE_RING - 1; ++j)
-                if (j < plan.n_ops) fr[j % PIPE_RING] = fragment(plan.ops[j]);
-#pragma unroll
-            for (int gi = 0; gi < plan.n; ++gi) {
-                const PipeGroup G = plan.g[gi];
-                if (G.op >= 0) {
-                    const PipeOp op = plan.ops[G.op];
-                    if (G.op + PIPE_RING - 1 < plan.n_ops) fr[(G.op + PIPE_RING - 1) % PIPE_RING] = fragment(plan.ops[G.op + PIPE_RING - 1]);
-                    const f16x8 af = fr[G.op % PIPE_RING];
-                    if (op.type == 1)
-                        sn[op.kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, qf[op.idx], op.idx == 0 ? (f32x16)0.f : sn[op.kt], 0, 0, 0);
-                    else
-                        o[op.idx % DV] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, pk[op.kt][op.idx / DV], o[op.idx % DV], 0, 0, 0);
-                }
-                if (G.piece >= 0) {
-                    const int kt = G.piece_kt, st = G.piece >= 2;
-                    // (the empty volatile asm statements pin a piece's results to its group: pure operations carry no order
-                    // against sched_barrier before the machine scheduler sees them — left alone the row-sum dot products and
-                    // the maxima of the next chunk sink to the end of the block, out from under the MFMAs)
-                    if (kt == 4) {
-                        mxn = tile_max(sn[G.piece], mxn);
-                        asm volatile("" : "+v"(mxn));
-                    } else {
-                        if (G.piece == 2 || G.piece == 4) {
-                            softmax_sum4(pp[kt][G.piece == 4], psum);
-                            pk[kt][G.piece == 4] = softmax_pack(pp[kt][G.piece == 4]);
-                            asm volatile("" : "+v"(psum), "+v"(pk[kt][G.piece == 4]));
-                        }
-                        if (G.piece == 0 || G.piece == 2) {
-                            aa[kt][st] = softmax_args4(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
-                                                       s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new);
-                            asm volatile("" : "+v"(aa[kt][st]));
-                        }
-                        if (G.piece == 1 || G.piece == 3) {
-                            pp[kt][G.piece == 3] = softmax_exp4(aa[kt][G.piece == 3]);
-                            asm volatile("" : "+v"(pp[kt][G.piece == 3]));
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            psum += __shfl_xor(psum, 32);
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dv = 0; dv < DV; ++dv) vbase[dv] += CH;
-            if constexpr (NEXT) {
-#pragma unroll
-                for (int kk = 0; kk < KS; ++kk) kbase[kk] += CH * K_ROW;
-                mx = mxn;
-                if (kc + 2 * CH > n) {                   // the following chunk is the sentence's ragged last one
-                    asm volatile("; ragged last chunk" ::: "memory");
-                    mask_tail(sn, kc + CH);
-                    mx = -INFINITY;
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) mx = tile_max(sn[kt], mx);
-                }
-            }
-        };
-        f32x16 s2[KT];
-        for (int kc = 0;; kc += 2 * CH) {
-            if (!(PIPE && kc + CH < n_steps)) { chunk(std::false_type{}, kc, s, s2); break; }
-            chunk(std::true_type{}, kc, s, s2);
-            if (!(kc + 2 * CH < n_steps)) { chunk(std::false_type{}, kc + CH, s2, s); break; }
-            chunk(std::true_type{}, kc + CH, s2, s);
-        }
-#else      // the straight-line chunk loop of rounds 1-4 (tuning builds: -DBERT_HIP_ATT_PIPE=0)
         constexpr int KT = CH / 32;                    // key tiles per step
         const int n_steps = (n + CH - 1) / CH * CH;      // (whole steps of padding are skipped: their keys are masked out anyway)
         for (int kc = 0; kc < n_steps; kc += CH) {
             // ---- S^T chunk: KT key tiles x 16 regs; reg r of tile kt <-> key kc + kt*32 + (r&3) + 8*(r>>2) + 4*hi
             f32x16 s[KT];
+            // (key tile outside, k-step inside: an accumulator's MFMAs back to back.  The other nest — four accumulators in turn, no
+            // MFMA behind its predecessor's result — is 1.5x SLOWER in this phase: 3.6 k against 2.35 k cycles per chunk in the phase
+            // clock of round 5, attention at 512 tokens 11.5 against 8.4 ms per 12 launches)
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -355,6 +231,13 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             }
 #pragma unroll
             for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
+            if (MULTI && kc + CH >= n_steps && qb + NT / 64 < n_qblocks) {
+                const int qrow = min((qb + NT / 64) * 32 + l31, n - 1);
+                const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
+#pragma unroll
+                for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
+            }
+            ATT_TL(asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); ATT_MARK(1) asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); ++tl_chunks;)
             // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
             if (kc + CH > n) {
 #pragma unroll
@@ -390,6 +273,8 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             for (int dv = 0; dv < D / 32; ++dv)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
+            ATT_TL(asm volatile("" : "+v"(pfr[0][0]), "+v"(pfr[1][1]), "+v"(pfr[2][0]), "+v"(pfr[3][1]), "+v"(o[0]), "+v"(l_run)); ATT_MARK(2)
+                   asm volatile("" : "+v"(pfr[0][0]), "+v"(pfr[1][1]), "+v"(pfr[2][0]), "+v"(pfr[3][1]), "+v"(o[0]), "+v"(l_run));)
             // ---- O^T += V^T * P^T
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
@@ -409,8 +294,8 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 }
 #pragma unroll
             for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += CH;
+            ATT_TL(asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1])); ATT_MARK(3) asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1]));)
         }
-#endif
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
         const int q = qb * 32 + l31;
         if (q < n) {
@@ -426,7 +311,25 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     *(f16x4 *)(op + dv * 32 + 8 * g + 4 * hi) = ov;
                 }
         }
+        ATT_MARK(4)
     }
+    }      // n > 0
+    else if (PERSIST && v + (int)gridDim.x < n_items) {
+        // (an empty sentence: nothing to compute, but the walk goes on and the next item's rows must be under way)
+        nxt = item_of(v + (int)gridDim.x);
+        __syncthreads();                               // (kv / vv hold nothing of value for an empty item; keep the waves together)
+        if (nxt.n > 0) request(nxt, tid);
+    }
+    v += (int)gridDim.x;
+    if (!PERSIST || v >= n_items) break;
+    cur = nxt;
+    }      // items
+    ATT_TL(if ((tid & 255) == 0) {
+        unsigned long long *tl = g_timeline + (blockIdx.x & 1023) * 256 + (tid >> 8) * 16;
+        for (int k = 0; k < 6; ++k) tl[k] = (unsigned long long)tl_sum[k];
+        tl[6] = (unsigned long long)(att_clock() - tl_t00); tl[7] = (unsigned long long)tl_chunks;
+    })
+#undef ATT_MARK
 }
 
 template <int D>
@@ -435,19 +338,40 @@ static void launch_att(const half_t *qkv, const int32_t *cu, int B, int n_head, 
     const int n_pad = (max_len + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK;
     const size_t lds = (size_t)n_pad * D * 2 + (size_t)D * (n_pad + VT_PAD) * 2;
     // per device: the opt-in is a per-device attribute; the devices of a context launch from threads of their own
-    static DeviceFlags configured[3];
+    static DeviceFlags configured[2];
     const bool wide = n_pad > 128;
-    // (tuning: BERT_HIP_ATT_WAVES=4 runs long sentences with one wave per SIMD instead of two)
-    static const bool four = [] { const char *e = getenv("BERT_HIP_ATT_WAVES"); return e && atoi(e) == 4; }();
     if (lds > 64 * 1024)
-        configure_once(configured[wide ? (four ? 2 : 1) : 0], [&] {                 // (once, for the largest LDS the kernel can be launched with)
-            if (wide && four) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            else if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configure_once(configured[wide], [&] {                 // (once, for the largest LDS the kernel can be launched with)
+            if (wide) (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 512, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             else (void)hipFuncSetAttribute((const void *)attention_mfma_kernel<D, 256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         });
-    if (wide && four) BERT_LAUNCH((attention_mfma_kernel<D, 256, 128, true>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
-    else if (wide) BERT_LAUNCH((attention_mfma_kernel<D, 512, 128>), dim3(B * n_head), dim3(512), lds, s, qkv, cu, n_head, out);
-    else BERT_LAUNCH((attention_mfma_kernel<D, 256, 128>), dim3(B * n_head), dim3(256), lds, s, qkv, cu, n_head, out);
+    const int items = B * n_head;
+    // the persistent form: one workgroup per CU (a multiple of 8: a workgroup's items stay on its XCD)
+    static int n_cu[MAX_HIP_DEVICES] = {};
+    const int dev = current_device_slot();
+    if (!n_cu[dev]) {
+        hipDeviceProp_t prop;
+        n_cu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : 256;
+    }
+    const int pgrid = items >= 8 ? std::min(n_cu[dev], items / 8 * 8) : items;
+    if (wide) BERT_LAUNCH((attention_mfma_kernel<D, 512, 128>), dim3(pgrid), dim3(512), lds, s, qkv, cu, n_head, out, items);
+    else BERT_LAUNCH((attention_mfma_kernel<D, 256, 128>), dim3(items), dim3(256), lds, s, qkv, cu, n_head, out, items);
+#ifdef BERT_HIP_TIMELINE
+    {
+        static int shots = 0;
+        if (wide && shots++ == 20) {
+            (void)hipDeviceSynchronize();
+            static unsigned long long h[1024 * 256];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_timeline), sizeof(h));
+            fprintf(stderr, "attention phase clock, shader cycles summed per wave over its items (workgroup: wave 0 | wave 4): staging S softmax PV store between total chunks\n");
+            for (int b : {0, 1, 2, 100, 200, 255})
+                for (int w = 0; w < 2; ++w) {
+                    const unsigned long long *t = h + b * 256 + w * 16;
+                    fprintf(stderr, "attphase wg %3d wave %d: %8llu %8llu %8llu %8llu %8llu %8llu | %9llu  %llu\n", b, 4 * w, t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+                }
+        }
+    }
+#endif
 }
 
 bool launch_attention_mfma(const half_t *qkv, const int32_t *cu_seqlens, int n_sentences, int n_head, int d_head,

@@ -49,9 +49,21 @@ struct bert_ctx {
     // through a 1-rank communicator on a single device
     bool inject_bad_alloc = false, rccl_single = false;
     Engine *engine() const { return engines.empty() ? nullptr : engines[0].get(); }
-    // device-resident results of bert_hip_eval_packed_gather: shard buffers and the gathered matrix, per device
+    // device-resident results of bert_hip_eval_packed_gather: shard buffers (two per device: super-batch k + 1 is computed
+    // into one while the exchange of super-batch k reads the other) and the gathered matrix, per device
     std::vector<std::unique_ptr<DevBuf>> shard_out, gathered;
+    // the exchange's own stream per device and an event per (device, shard buffer): "the exchange that read this buffer is done"
+    std::vector<hipStream_t> xstream;
+    std::vector<hipEvent_t> xdone;
+    int gather_super_tokens = 0;        // option "gather_super_tokens": tokens per device and super-batch (0: four device chunks)
     RcclGather rccl;
+    ~bert_ctx() {
+        for (size_t d = 0; d < xstream.size(); ++d) {
+            if (d < engines.size()) (void)hipSetDevice(engines[d]->device());
+            if (xstream[d]) { (void)hipStreamSynchronize(xstream[d]); (void)hipStreamDestroy(xstream[d]); }
+        }
+        for (hipEvent_t e : xdone) if (e) (void)hipEventDestroy(e);
+    }
 };
 
 namespace {
@@ -465,67 +477,98 @@ int32_t bert_hip_eval_packed(struct bert_ctx *ctx, const bert_vocab_id *tokens, 
 int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *tokens, const int32_t *cu_seqlens,
                                     int32_t n_sentences, float **d_embeddings) {
     return guarded("bert_hip_eval_packed_gather", (int32_t)-4, [&]() -> int32_t {
-        if (!ctx->engine()) { fprintf(stderr, "bert_hip_eval_packed_gather: tokenizer-only context\n"); return -1; }
+        const char *me = "bert_hip_eval_packed_gather";
+        if (!ctx->engine()) { fprintf(stderr, "%s: tokenizer-only context\n", me); return -1; }
         if (n_sentences <= 0) return 0;
         for (int32_t b = 0; b < n_sentences; ++b)
             if (!sentence_ok(ctx, tokens + cu_seqlens[b], cu_seqlens[b + 1] - cu_seqlens[b])) return -2;
         const int n_dev = (int)ctx->engines.size(), H = ctx->hp.n_embd;
+        const bool exchange = n_dev > 1 || ctx->rccl_single;      // (test_rccl_single: a single device runs the step on a 1-rank communicator)
         std::string err;
-        // per device: a buffer for its own shard and the gathered [n_sentences][H] matrix (grow-only, owned by the context)
+        auto fail = [&](const std::string &what) { fprintf(stderr, "%s: %s\n", me, what.c_str()); return (int32_t)-3; };
+        // per device: two shard buffers and the gathered [n_sentences][H] matrix (grow-only, owned by the context)
         if (ctx->shard_out.empty())
-            for (int d = 0; d < n_dev; ++d) { ctx->shard_out.emplace_back(new DevBuf); ctx->gathered.emplace_back(new DevBuf); }
-        std::vector<int> bounds;
-        shard_bounds(cu_seqlens, n_sentences, n_dev, bounds);
-        std::vector<float *> src((size_t)n_dev), dst((size_t)n_dev);
-        std::vector<hipStream_t> streams((size_t)n_dev);
+            for (int d = 0; d < 2 * n_dev; ++d) { ctx->shard_out.emplace_back(new DevBuf); if (d < n_dev) ctx->gathered.emplace_back(new DevBuf); }
+        // SUPER-BATCHES ("one gather per super-batch, overlapped with the next super-batch's compute"): the call is
+        // cut into runs of sentences of about `super` tokens per device; every run is sharded over the devices by token count
+        // like a call of its own, and its exchange is issued on the devices' EXCHANGE streams as soon as its shards are
+        // computed — it runs under the next run's compute.  Rows land at their global positions, so the result does not depend
+        // on the cut.  A call that fits one run is one shard per device and one exchange, as before.
+        const long long super = ctx->gather_super_tokens > 0 ? ctx->gather_super_tokens : 4ll * 262144;
+        std::vector<int> runs{0};
+        if (exchange) {
+            const long long per_run = super * n_dev;
+            for (int b = 1; b <= n_sentences; ++b)
+                if (b == n_sentences || (long long)cu_seqlens[b + 1] - cu_seqlens[runs.back()] > per_run) runs.push_back(b);
+        } else {
+            runs.push_back(n_sentences);
+        }
+        const int n_runs = (int)runs.size() - 1;
+        // every fallible preparation happens before any rank enters RCCL: a rank that fails between its peers' collectives leaves
+        // them waiting in a collective that never completes
+        std::vector<int> devs;
+        for (auto &e : ctx->engines) devs.push_back(e->device());
+        size_t max_rows = 1;
+        std::vector<std::vector<int>> run_bounds((size_t)n_runs);
+        for (int k = 0; k < n_runs; ++k) {
+            shard_bounds(cu_seqlens + runs[k], runs[k + 1] - runs[k], n_dev, run_bounds[k]);
+            for (int d = 0; d < n_dev; ++d) max_rows = std::max(max_rows, (size_t)(run_bounds[k][d + 1] - run_bounds[k][d]));
+        }
+        if (exchange && (int)ctx->xstream.size() < n_dev) { ctx->xstream.resize(n_dev, nullptr); ctx->xdone.resize(2 * n_dev, nullptr); }
+        std::vector<float *> dst((size_t)n_dev);
         for (int d = 0; d < n_dev; ++d) {
-            if (hipSetDevice(ctx->engines[d]->device()) != hipSuccess) { fprintf(stderr, "bert_hip_eval_packed_gather: hipSetDevice failed\n"); return -3; }
-            // (a single device gathers nothing: its shard buffer IS the result)
-            if (!ctx->shard_out[d]->ensure((size_t)std::max(1, bounds[d + 1] - bounds[d]) * H * 4, err) ||
-                (n_dev > 1 && !ctx->gathered[d]->ensure((size_t)n_sentences * H * 4, err))) {
-                fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
-                return -3;
+            if (hipSetDevice(devs[d]) != hipSuccess) return fail("hipSetDevice failed");
+            for (int sl = 0; sl < (n_runs > 1 ? 2 : 1); ++sl)
+                if (!ctx->shard_out[2 * d + sl]->ensure(max_rows * H * 4, err)) return fail(err);
+            if (exchange && !ctx->gathered[d]->ensure((size_t)n_sentences * H * 4, err)) return fail(err);
+            // (no exchange: the one device's shard buffer IS the result)
+            dst[d] = exchange ? ctx->gathered[d]->as<float>() : ctx->shard_out[2 * d]->as<float>();
+            if (exchange) {
+                if (!ctx->xstream[d] && hipStreamCreateWithFlags(&ctx->xstream[d], hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+                for (int sl = 0; sl < 2; ++sl)
+                    if (!ctx->xdone[2 * d + sl] && hipEventCreateWithFlags(&ctx->xdone[2 * d + sl], hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
             }
-            src[d] = ctx->shard_out[d]->as<float>();
-            dst[d] = n_dev > 1 ? ctx->gathered[d]->as<float>() : src[d];
-            streams[d] = ctx->engines[d]->stream();
         }
-        if (eval_packed_all_devices(ctx, tokens, cu_seqlens, n_sentences, nullptr, err, nullptr, src.data()) != 0) {
-            fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
-            return -3;
-        }
-        // the one exchange step of the path: every device receives every other device's shard (RCCL over xGMI).  With the
-        // option test_rccl_single a single device runs it too (a 1-rank communicator), to exercise the code on one GPU.
-        if (n_dev > 1 || ctx->rccl_single) {
-            std::vector<int> devs;
-            for (auto &e : ctx->engines) devs.push_back(e->device());
-            if (n_dev == 1) {
-                if (!ctx->gathered[0]->ensure((size_t)n_sentences * H * 4, err)) { fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str()); return -3; }
-                dst[0] = ctx->gathered[0]->as<float>();
+        if (exchange && !ctx->rccl.init(devs, err)) return fail(err);
+        const bool threaded = exchange && ctx->workers && ctx->workers->n_threads() == n_dev - 1;
+        for (int k = 0; k < n_runs; ++k) {
+            const int sl = k & 1, b0 = runs[k], nb = runs[k + 1] - b0;
+            std::vector<float *> src((size_t)n_dev);
+            for (int d = 0; d < n_dev; ++d) {
+                src[d] = ctx->shard_out[2 * d + sl]->as<float>();
+                // the exchange of run k - 2 read this buffer
+                if (exchange && k >= 2 && (hipSetDevice(devs[d]) != hipSuccess || hipEventSynchronize(ctx->xdone[2 * d + sl]) != hipSuccess))
+                    return fail("waiting for an exchange failed");
             }
-            bool ok = ctx->rccl.init(devs, err);
-            if (ok && ctx->workers && ctx->workers->n_threads() == n_dev - 1) {
+            // (blocking: the shards are complete in src when this returns)
+            if (eval_packed_all_devices(ctx, tokens, cu_seqlens + b0, nb, nullptr, err, nullptr, src.data()) != 0) return fail(err);
+            if (!exchange) break;
+            // this run's exchange step (RCCL over xGMI): every device receives every other device's shard of the run, at rows
+            // b0 + bounds of its matrix; not waited for here
+            const std::vector<int> &bounds = run_bounds[k];
+            bool ok;
+            if (threaded) {
                 // every device's call from the host thread that serves the device (worker d - 1, the caller for device 0)
                 std::vector<int> each((size_t)n_dev + 1);
                 for (int d = 0; d <= n_dev; ++d) each[d] = d;
                 std::vector<std::string> errs((size_t)n_dev);
                 const int rc = ctx->workers->run(each, [&](int d, int, int) {
-                    return ctx->rccl.exchange_on(d, src[d], dst[d], bounds, H, streams[d], errs[d]) ? 0 : -3; }, &err);
+                    return ctx->rccl.exchange_on(d, src[d], dst[d] + (size_t)b0 * H, bounds, H, ctx->xstream[d], errs[d]) ? 0 : -3; }, &err);
                 for (auto &e : errs) if (err.empty() && !e.empty()) err = e;
                 ok = rc == 0;
-            } else if (ok) {
-                ok = ctx->rccl.all_gather(src.data(), dst.data(), bounds, H, streams.data(), err);
+            } else {
+                std::vector<float *> at((size_t)n_dev);
+                for (int d = 0; d < n_dev; ++d) at[d] = dst[d] + (size_t)b0 * H;
+                ok = ctx->rccl.all_gather(src.data(), at.data(), bounds, H, ctx->xstream.data(), err);
             }
-            if (!ok) {
-                fprintf(stderr, "bert_hip_eval_packed_gather: %s\n", err.c_str());
-                return -3;
-            }
+            if (!ok) return fail(err);
+            for (int d = 0; d < n_dev; ++d)
+                if (hipSetDevice(devs[d]) != hipSuccess || hipEventRecord(ctx->xdone[2 * d + sl], ctx->xstream[d]) != hipSuccess) return fail("hipEventRecord failed");
         }
         for (int d = 0; d < n_dev; ++d) {
-            if (hipSetDevice(ctx->engines[d]->device()) != hipSuccess || hipStreamSynchronize(streams[d]) != hipSuccess) {
-                fprintf(stderr, "bert_hip_eval_packed_gather: synchronisation failed\n");
-                return -3;
-            }
+            if (hipSetDevice(devs[d]) != hipSuccess || hipStreamSynchronize(ctx->engines[d]->stream()) != hipSuccess ||
+                (exchange && hipStreamSynchronize(ctx->xstream[d]) != hipSuccess))
+                return fail("synchronisation failed");
             d_embeddings[d] = dst[d];
         }
         return 0;
@@ -612,6 +655,7 @@ void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *valu
         if (!key || !value) return;
         if (strcmp(key, "test_inject_bad_alloc") == 0) ctx->inject_bad_alloc = *value == '1';
         else if (strcmp(key, "test_rccl_single") == 0) ctx->rccl_single = *value == '1';
+        else if (strcmp(key, "gather_super_tokens") == 0) ctx->gather_super_tokens = std::max(0, atoi(value));
         else
             for (auto &e : ctx->engines) e->set_option(key, value);
     });

@@ -27,18 +27,23 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 // Softmax numerators of EIGHT scores of one query (registers 8 st .. 8 st + 7 of an S^T tile = the B fragment of one P·V MFMA
-// step), in the reference's own precision: ggml's soft_max rounds (s - max) to fp16 and reads an fp16 table of exp
-// (reference bert.cpp:845 -> ggml_soft_max; oracle/bert_oracle.cpp:544), sums in higher precision and rounds P to f16 again
-// for the V mat-mul.  Here: the argument s * sc - m is ONE fma rounded once to f16 (v_fma_mixlo / mixhi_f16 write the two
-// halves of a register: no conversion instruction), the exponential is v_exp_f16 on each half (the high one through SDWA with
-// the low half preserved: no pack), the pair IS the MFMA operand, and the row sum stays f32 (v_dot2c_f32_f16 with (1, 1): one
-// instruction per pair).  16 VALU + 4 dot2 per 8 scores against 28 for fma / v_exp_f32 / add / v_cvt_pk_f16_f32 — the attention
-// waves are VALU-bound.  All attention bodies (attention.hip, qkv_attention2.hip and with it model_kernel.hip)
-// call this one function: equal bits across the routes.
-// The trailing s_nop: gfx940+ needs one wait state between an instruction that writes half a register (SDWA dst_sel) and a
-// reader of that register, and the compiler's hazard pass does not look into an asm block.
+// step) — ONE function for all attention bodies (attention.hip, qkv_attention2.hip and with it model_kernel.hip): equal bits
+// across the routes.  Two forms:
+//   BERT_HIP_EXP16 = 0 (default): p = exp2(fma(s, sc, -m)) in f32 (v_fma_f32, v_exp_f32), the row sum an f32 add, P rounded to
+//     f16 for the V mat-mul (v_cvt_pk_f16_f32) — rounds 1-4's arithmetic.
+//   BERT_HIP_EXP16 = 1: the reference's own precision — ggml's soft_max rounds (s - max) to fp16 and reads an fp16 table of exp
+//     (reference bert.cpp:845 -> ggml_soft_max; oracle/bert_oracle.cpp:544): the argument one fma rounded ONCE to f16
+//     (v_fma_mixlo / mixhi_f16 write the two halves of a register), v_exp_f16 on each half (the high one through SDWA with the
+//     low half preserved), the pair IS the MFMA operand, the row sum f32 through v_dot2c_f32_f16 with (1, 1).  21 instructions
+//     per 8 scores against 28 — and SLOWER on this chip (round 5, tools/ubench/valu_cost.hip, profiles/r5_valu_cost.txt):
+//     v_fma_mix* issue at the transcendental rate (7.9 cycles per instance and wave beside MFMAs, 2 waves per SIMD, against 2.5
+//     for v_fma_f32) and v_dot2c shares the matrix pipe (8.6 against 1.9 for v_add_f32): 40 cycles per score pair against 27.
+//     Measured end to end: headline 327.0 k against 330.5 k sentences/s on one box, attention at 512 tokens 9.28 against 8.68 ms
+//     per 12 launches.  Parity-green (395 tests) and kept as a build option; not the default.
+// The trailing s_nop of the fp16 form: gfx940+ needs one wait state between an instruction that writes half a register (SDWA
+// dst_sel) and a reader of that register, and the compiler's hazard pass does not look into an asm block.
 #ifndef BERT_HIP_EXP16
-#define BERT_HIP_EXP16 1
+#define BERT_HIP_EXP16 0
 #endif
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x8_t __attribute__((ext_vector_type(8)));

@@ -239,15 +239,19 @@ bool RcclGather::all_gather(float *const *src, float *const *dst, const std::vec
                             std::string &err) {
     const int n = (int)comms_.size();
     if ((int)bounds.size() != n + 1) { err = "RcclGather: shard count does not match the communicator"; return false; }
+    // (what can fail outside RCCL fails before the group is opened: a group closed over some ranks' calls only leaves those
+    // ranks in a collective their peers never join)
+    for (int d = 0; d < n; ++d)
+        if (hipSetDevice(devices_[d]) != hipSuccess) { err = "RCCL exchange: hipSetDevice failed"; return false; }
     // one host thread drives every device's communicator: the calls of the n ranks form ONE group
     int rc = ((fn_group)fn_[F_GSTART])();
     for (int d = 0; rc == 0 && d < n; ++d) {
-        if (hipSetDevice(devices_[d]) != hipSuccess) { rc = -1; break; }
+        (void)hipSetDevice(devices_[d]);
         rc = issue(d, src[d], dst[d], bounds, H, streams[d], false);
     }
     const int rc2 = ((fn_group)fn_[F_GEND])();
     if (rc == 0) rc = rc2;
-    if (rc != 0) { err = rc < 0 ? std::string("RCCL exchange: hipSetDevice failed") : std::string("RCCL exchange: ") + ((fn_err)fn_[F_ERR])(rc); return false; }
+    if (rc != 0) { err = std::string("RCCL exchange: ") + ((fn_err)fn_[F_ERR])(rc); return false; }
     return true;
 }
 
