@@ -55,7 +55,7 @@ def _worker(rank, world, port, model_path, n_sent, seed, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_sent", [(2, 9), (2, 1), (3, 2)])
+@pytest.mark.parametrize("world,n_sent", [(2, 9), (2, 1), (3, 2), (8, 37)])        # (8: the node's rank count)
 def test_sharded_encode_matches_single_process(tmp_path, world, n_sent):
     import torch.multiprocessing as mp
 

@@ -158,6 +158,18 @@ def test_gather_entry_point_matches_the_host_api(make_model, monkeypatch):
         assert len(ptrs) == m.n_devices() >= 1
         for d, p in enumerate(ptrs):
             assert np.array_equal(hip.download(p, (len(lens), hp.n_embd), device=d), want), (force, d)
+    # SUPER-BATCHES: with few tokens per run the call is cut into many runs, each sharded and exchanged on
+    # its own — the exchange of run k on the exchange stream while run k + 1 computes, two shard buffers in turn.  Rows land
+    # at their global positions: the same matrix, whatever the cut (1 / 2 / 3 / 7 / 19 runs here).
+    for super_tokens in (100000, 10000, 7000, 3000, 1000):
+        m.set_option("gather_super_tokens", str(super_tokens))
+        ptrs = m.eval_packed_gather(toks, cu)
+        for d, p in enumerate(ptrs):
+            assert np.array_equal(hip.download(p, (len(lens), hp.n_embd), device=d), want), (super_tokens, d)
+    m.set_option("gather_super_tokens", "0")
+    # back-to-back calls reuse buffers, streams and events
+    for _ in range(3):
+        assert np.array_equal(hip.download(m.eval_packed_gather(toks, cu)[0], (len(lens), hp.n_embd), device=0), want)
 
 
 @pytest.mark.gpu

@@ -1,8 +1,8 @@
 export TMPDIR=/tmp BERT_HIP_QUIET=1
 OUT=$PWD/gpurun_out; mkdir -p $OUT
-timeout 120 python tools/latency_probe.py 128 300
-timeout 120 python tools/latency_probe.py 25 300
-cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_lat -o lat -- python $OUT/../tools/latency_probe.py 128 200 > $OUT/lat_prof.log 2>&1
+timeout 120 python tools/probe.py latency 128 300
+timeout 120 python tools/probe.py latency 25 300
+cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_lat -o lat -- python $OUT/../tools/probe.py latency 128 200 > $OUT/lat_prof.log 2>&1
 cd $OUT/..; DB=$(find $OUT/prof_lat -name '*_results.db' | head -1)
 python tools/rocpd_summary.py stats $DB | head -20
 python tools/rocpd_summary.py gaps $DB | head -20
