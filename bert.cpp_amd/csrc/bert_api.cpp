@@ -45,6 +45,7 @@ struct bert_ctx {
     // host threads of the batch tokenizer (bert_encode_batch / bert_hip_tokenize_batch), created at the first call that asks for
     // them and kept: a group of 4096 texts tokenizes in about a millisecond, sixteen thread starts cost a third of that
     mutable std::unique_ptr<ShardWorkers> tok_workers;
+    mutable int tok_workers_asked = 0;
     // test knobs (bert_hip_set_option "test_inject_bad_alloc" / "test_rccl_single"): the ABI's catch-all; the exchange step
     // through a 1-rank communicator on a single device
     bool inject_bad_alloc = false, rccl_single = false;
@@ -350,8 +351,10 @@ void bert_eval(struct bert_ctx *ctx, int32_t n_threads, bert_vocab_id *tokens, i
     bert_eval_batch(ctx, n_threads, 1, &tokens, &n_tokens, embeddings ? &embeddings : nullptr);
 }
 
-// Tokenizes n_inputs texts into tokens[i * n_max_tokens ..] on up to n_threads host threads (the tokenizer is
-// const and re-entrant; inputs are handed out in blocks of 16 from a shared counter).
+// Tokenizes n_inputs texts into tokens[i * n_max_tokens ..] on up to n_threads host threads (the tokenizer itself is const
+// and re-entrant; inputs are handed out in blocks of 16 from a shared counter).  The persistent worker pool belongs to the
+// context and is created / grown here: like every entry point of a bert_ctx this function is NOT re-entrant on one context
+// (calls are serialised by the caller; bert_encode_batch's tokenize-ahead thread is the only caller while it runs).
 static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts,
                           bert_vocab_id *tokens, int32_t *n_tokens) {
     const int32_t N = ctx->hp.n_max_tokens;
@@ -371,7 +374,9 @@ static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inpu
         }
     };
     // persistent workers (a thread that could not be started is not an error: the others, at least the caller, take its share)
-    if (!ctx->tok_workers || ctx->tok_workers->n_threads() < nt - 1) ctx->tok_workers.reset(new ShardWorkers(nt - 1));
+    // (rebuilt only when MORE threads are asked for than were ever asked for: a pool that came up short — a thread that could
+    // not be started — is kept, not torn down and recreated on every call)
+    if (!ctx->tok_workers || ctx->tok_workers_asked < nt - 1) { ctx->tok_workers.reset(new ShardWorkers(nt - 1)); ctx->tok_workers_asked = nt - 1; }
     std::vector<int> each((size_t)nt + 1);
     for (int k = 0; k <= nt; ++k) each[k] = k;                   // "shard" k = worker k's turn at the shared counter
     std::string err;

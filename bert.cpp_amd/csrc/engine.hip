@@ -367,6 +367,10 @@ void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
         f();
         if (replay_done_ || replay_name_ != name) return;
         replay_done_ = true;
+        // (in-place kernels run on their own output from here on: this pass's embeddings are NOT results — bench.py restores
+        // its output buffer; say so once for anybody else who turns the option on)
+        static bool warned = false;
+        if (!warned && !getenv("BERT_HIP_QUIET")) { warned = true; fprintf(stderr, "bert_hip: profile_replay is active: the embeddings of profiled passes are not valid results\n"); }
         Pending p{name, get(), get(), flops * replay_k_, replay_k_};
         (void)hipEventRecord(p.a, s);
         for (int k = 0; k < replay_k_; ++k) f();
@@ -376,11 +380,14 @@ void Engine::timed(const char *name, double flops, hipStream_t s, F &&f) {
     }
     // an event pair attached to the dispatch itself (kernels.h BERT_LAUNCH): an upper bound of the kernel's time in the pass
     Pending p{name, get(), get(), flops, 1};
-    const LaunchTiming lt{p.a, p.b};
+    LaunchTiming lt{p.a, p.b, 0};
     tl_launch_timing = &lt;
     f();
     tl_launch_timing = nullptr;
-    pending_.push_back(p);
+    // exactly one launch carries the pair; anything else (a launcher that returned early: stale timestamps of pooled events;
+    // several launches: only the last one measured) is not a sample
+    if (lt.launches == 1) pending_.push_back(p);
+    else { ev_pool_.push_back(p.a); ev_pool_.push_back(p.b); }
 }
 
 void Engine::profile_enable(bool on) { profiling_ = on; }

@@ -288,14 +288,17 @@ inline void configure_once(DeviceFlags &seen, F &&opt_in) {
 // still reads long — model_kernel 825-866 us against 780 us in rocprofv3's trace of the same steps — whatever the events'
 // fence flags; for kernels of a millisecond and more the two agree within 1 %.  These times feed the per-kernel BREAKDOWN; the
 // roofline's kernel time comes from replay groups (engine.hip timed(), bench.py kernel_roofline).
-struct LaunchTiming { hipEvent_t start, stop; };
-inline thread_local const LaunchTiming *tl_launch_timing = nullptr;
+// `launches` counts the launches a timed body issued: the event pair is only meaningful for exactly one (a body that returns
+// without launching leaves stale timestamps in pooled events, a body with two launches measures the last one).
+struct LaunchTiming { hipEvent_t start, stop; int launches; };
+inline thread_local LaunchTiming *tl_launch_timing = nullptr;
 #define BERT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                     \
     do {                                                                                                                      \
-        if (::bert_hip::tl_launch_timing)                                                                                     \
+        if (::bert_hip::tl_launch_timing) {                                                                                   \
+            ++::bert_hip::tl_launch_timing->launches;                                                                         \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ::bert_hip::tl_launch_timing->start,                      \
                                   ::bert_hip::tl_launch_timing->stop, 0, __VA_ARGS__);                                        \
-        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                               \
+        } else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                             \
     } while (0)
 
 // The f32 route (f32_route.hip): the forward pass of f32 model files in f32 arithmetic — f32 activations, mat-muls on

@@ -6,7 +6,7 @@ import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
 P = os.path.join(root, "profiles")
@@ -45,10 +45,12 @@ for k in ("model_kernel", "layer_tail", "qkv_attention2"):
     except StopIteration:
         pass
 bench_text = [l for l in read(f"bench_{tag}.log").splitlines() if l.startswith("{")][-1]      # (RCCL prints its banner to stdout too)
-bench = json.loads(bench_text)
+line = json.loads(bench_text)                  # the ONE compact line (what the driver parses)
+assert len(bench_text) < 6144, len(bench_text)
+bench = json.loads(read(f"bench_detail_{tag}.json"))      # the full detail the same run wrote beside it (bench_detail.json)
 hdr = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --repeat 2 --no-cpu-baseline --also   (MI355X, round {tag[1:]}, commit {commit}; tools/gpu_round_check.sh)\n"
        f"# config: all-MiniLM-L6-v2 dims f16, 256 x 128 tokens per step, 6 layers: ONE launch for all layers (model_kernel: a workgroup per window, qkv_attention2 + layer_tail as phases)\n"
-       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_to_host']['value'] / 1e3:.1f} k), its own time of {bench['roofline']['kernel']} ({bench['roofline']['timing']}): {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
+       f"# same box, un-profiled default bench line: {bench['value'] / 1e3:.1f} k sentences/s (device-resident; host to host {bench['host_api']['value'] / 1e3:.1f} k; bert_eval_batch {bench['eval_batch_api']['value'] / 1e3:.1f} k), its own time of {bench['roofline']['kernel']} ({bench['roofline']['timing']}): {bench['roofline']['avg_launch_us']:.1f} us per launch\n"
        "# MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): " +
        ", ".join(f"{k} {v[0] / 1e6:.2f} M / (1024 x {v[1] / 1e3:.1f} k) = {v[2]:.2f}" for k, v in busy.items()) + " (two launches per layer, earlier this round: layer_tail 0.41, qkv_attention2 0.34)\n")
 c3 = bench["also"]["config3"]
@@ -67,13 +69,16 @@ with open(os.path.join(P, "traffic.json"), "w") as f:
     f.write(read(f"traffic_{tag}.json"))
 with open(os.path.join(P, f"{tag}_bench_line.json"), "w") as f:
     f.write(bench_text + "\n")
+with open(os.path.join(P, f"{tag}_bench_detail.json"), "w") as f:
+    json.dump(bench, f, indent=1)
+    f.write("\n")
 # the line the bench printed UNDER rocprofv3 (the process whose kernel trace is {tag}_kernel_stats.txt): like with like
 prof_line = read(f"bench_prof_line_{tag}.txt").strip()
 if prof_line.startswith("{"):
     with open(os.path.join(P, f"{tag}_bench_line_profiled.json"), "w") as f:
         f.write(prof_line + "\n")
     pl = json.loads(prof_line)
-    print("under rocprofv3:", round(pl["value"]), "sentences/s,", pl["roofline"]["kernel"], round(pl["roofline"]["avg_launch_us"], 1), "us per launch (", pl["roofline"]["timing"][:60], "...)")
+    print("under rocprofv3:", round(pl["value"]), "sentences/s,", pl["roofline"]["kernel"], round(pl["roofline"]["avg_launch_us"], 1), "us per launch")
 cal = [l for l in read(f"gemm_calibration_{tag}.txt").splitlines() if "amdgpu.ids" not in l]
 with open(os.path.join(P, f"{tag}_gemm_calibration.txt"), "w") as f:
     f.write(f"# python tools/gemm_calibration.py on the box of this round check (commit {commit}): torch.matmul = hipBLASLt (Custom_Cijk_..._MT256x256x64_MI16x16x1 on the bert-base shapes), f16 in, f16 out, NO bias / GELU / residual;\n"

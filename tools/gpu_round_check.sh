@@ -7,13 +7,18 @@
 # usage (from the repo root on the GPU box):  bash tools/gpu_round_check.sh [tag]      then, here: python tools/assemble_profiles.py [tag]
 set -u
 trap '' PIPE        # (a reader that stops early — `| head` — must not end the run half way)
-TAG=${1:-r4}
+TAG=${1:-r5}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp BERT_HIP_QUIET=1
 timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_$TAG.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $OUT/pytest_$TAG.log | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke_$TAG.log 2>&1; echo "smoke rc=$?"
-timeout 900 python bench.py > $OUT/bench_$TAG.log 2> $OUT/bench_$TAG.err; echo "bench rc=$?"; cut -c1-600 $OUT/bench_$TAG.log
+t0=$(date +%s)
+timeout 900 python bench.py > $OUT/bench_$TAG.log 2> $OUT/bench_$TAG.err; echo "bench rc=$? [$(( $(date +%s) - t0 )) s] line bytes $(tail -1 $OUT/bench_$TAG.log | wc -c)"; cut -c1-600 $OUT/bench_$TAG.log
+cp bench_detail.json $OUT/bench_detail_$TAG.json
+# the driver's own invocation (its clock around the run is what BENCH_rNN.json records)
+t0=$(date +%s)
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_$TAG.log 2> $OUT/bench_driver_$TAG.err; echo "driver-style bench rc=$? [$(( $(date +%s) - t0 )) s] line bytes $(tail -1 $OUT/bench_driver_$TAG.log | wc -c)"
 
 cd /tmp
 # (100-step regions like the un-profiled line: a region's fixed costs — first launch, final synchronisation, the profiler's flush —
@@ -51,6 +56,11 @@ python tools/rocpd_summary.py pmc $(find $OUT/prof_fetch3_$TAG $OUT/prof_write3_
 python tools/pmc_traffic.py $TR > $OUT/traffic_$TAG.json 2>&1
 grep -h '^{' $OUT/bench_prof_$TAG.log | tail -1 > $OUT/bench_prof_line_$TAG.txt
 rm -rf $OUT/prof_stats_$TAG $OUT/prof_stats3_$TAG $OUT/prof_stats33_$TAG $OUT/prof_pmc*_$TAG $OUT/prof_fetch*_$TAG $OUT/prof_write*_$TAG
+# the attention kernel's phase clock (tuning build with -DBERT_HIP_TIMELINE, built by `make timeline`), instruction costs, the
+# shift experiment of the P.V accumulation
+if [ -f bert.cpp_amd/libbert_tl.so ]; then BERT_HIP_LIB=$PWD/bert.cpp_amd/libbert_tl.so timeout 200 python tools/probe.py kernels 3 2>&1 | grep -E "attphase|attention phase|cfg3" > $OUT/att_phase_$TAG.txt; fi
+[ -x tools/ubench/valu_cost ] && timeout 120 tools/ubench/valu_cost > $OUT/valu_cost_$TAG.txt 2>&1
+[ -x tools/ubench/mfma_shift ] && timeout 60 tools/ubench/mfma_shift > $OUT/mfma_shift_$TAG.txt 2>&1
 # calibration lines: the vendor GEMM library on the same shapes and box
 timeout 120 python tools/gemm_calibration.py > $OUT/gemm_calibration_$TAG.txt 2>&1; echo "calibration rc=$?"
 head -14 $OUT/stats_$TAG.txt
