@@ -219,7 +219,11 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             f32x16 s[KT];
             // (key tile outside, k-step inside: an accumulator's MFMAs back to back.  The other nest — four accumulators in turn, no
             // MFMA behind its predecessor's result — is 1.5x SLOWER in this phase: 3.6 k against 2.35 k cycles per chunk in the phase
-            // clock of round 5, attention at 512 tokens 11.5 against 8.4 ms per 12 launches)
+            // clock of round 5, attention at 512 tokens 11.5 against 8.4 ms per 12 launches.)
+            // (Measured and dropped in round 5: every fragment of this phase and of P·V requested TWO MFMAs ahead through a ring of three
+            // register sets, the order pinned by sched_barrier.  In isolation that is the better form — 39 against 66 cycles per MFMA with
+            // one wave on the SIMD, 56 against 68 per wave with two, tools/ubench/mfma_chain.hip — in this kernel it is 7 % slower:
+            // 9.04 against 8.42-8.47 ms per 12 launches at 512 tokens on one box, level at 128 tokens.)
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -275,13 +279,12 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 for (int r = 0; r < 16; ++r) o[dv][r] *= alpha;
             ATT_TL(asm volatile("" : "+v"(pfr[0][0]), "+v"(pfr[1][1]), "+v"(pfr[2][0]), "+v"(pfr[3][1]), "+v"(o[0]), "+v"(l_run)); ATT_MARK(2)
                    asm volatile("" : "+v"(pfr[0][0]), "+v"(pfr[1][1]), "+v"(pfr[2][0]), "+v"(pfr[3][1]), "+v"(o[0]), "+v"(l_run));)
-            // ---- O^T += V^T * P^T
+            // ---- O^T += V^T * P^T; keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int st = 0; st < 2; ++st) {
                     const f16x8 pf = pfr[kt][st];
-                    // keys key0..+3 and key0+8..+11 with key0 = kc + kt*32 + 16*st + 4*hi
 #pragma unroll
                     for (int dv = 0; dv < D / 32; ++dv) {
                         const lds_halfs vr = vbase[dv] + kt * 32 + 16 * st;
