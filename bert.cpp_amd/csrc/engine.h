@@ -43,6 +43,11 @@ struct GemmWeightStore {
 
 struct LayerWeights {
     GemmWeightStore qkv, o, ffi, ffo;
+    // q4 files with the default BERT_HIP_Q4=expand: the stacked Q | K | V matrix ALSO as 4-bit planes when its f16 image
+    // (3 H x H x 2 bytes) cannot stay in an XCD's 4 MiB L2 beside the activation tiles in flight — gemm256's persistent walk
+    // then re-fetches the f16 image every round (2.40 GB per launch at bert-base dims against 0.81 GB with the planes, which
+    // give the same bits and are 1-3 % faster on that launch: DESIGN.md §3).  Used by the QKV mat-mul of the gemm256 route only.
+    GemmWeightStore qkv_q4;
     DevBuf qkv_b, o_b, ffi_b, ffo_b, ln_att_w, ln_att_b, ln_out_w, ln_out_b;
 };
 

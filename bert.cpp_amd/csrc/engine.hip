@@ -265,6 +265,12 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         e->layers_.push_back(L);
         ok = ok && L->qkv.build({T(p + "attention.self.query.weight"), T(p + "attention.self.key.weight"),
                                  T(p + "attention.self.value.weight")}, want_naive, err, false, e->q4_expand_, want_f32);
+        {
+            const HostTensor *tq = T(p + "attention.self.query.weight");
+            const bool q4_file = tq && (tq->type == W_Q4_0 || tq->type == W_Q4_1);
+            if (ok && q4_file && e->q4_expand_ && L->qkv.mfma_ok && (size_t)L->qkv.w.N * L->qkv.w.K * 2 > ((size_t)3 << 20))
+                ok = L->qkv_q4.build({tq, T(p + "attention.self.key.weight"), T(p + "attention.self.value.weight")}, false, err, false, false);
+        }
         ok = ok && concat_upload(L->qkv_b, {T(p + "attention.self.query.bias"), T(p + "attention.self.key.bias"),
                                             T(p + "attention.self.value.bias")}, err);
         ok = ok && L->o.build({T(p + "attention.output.dense.weight")}, want_naive, err, false, e->q4_expand_, want_f32);
@@ -566,7 +572,9 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                 launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, d_n_windows, max_len, nh, ctx, s);
             });
         } else {
-            gemm("gemm_qkv", L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
+            // (q4 files: the 4-bit planes of the stacked matrix where its f16 image overflows an XCD's L2 and gemm256 takes the launch)
+            const bool planes = L.qkv_q4.w.qs && L.qkv_q4.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(L.qkv_q4.w, t_pad);
+            gemm("gemm_qkv", planes ? L.qkv_q4 : L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
             timed("attention", att_flops, s, [&] {
                 if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
                     launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);

@@ -857,7 +857,8 @@ def test_full_size_batch_properties_bert_base(make_model, q4, monkeypatch):
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention", "layernorm"} <= set(rep), sorted(rep)
     fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
-    assert fam == {"family:gemm256_q4" if q4 == "fused" else "family:gemm256_f16": 4 * hp.n_layer}, fam
+    # (default: the Q | K | V mat-mul runs on the 4-bit planes too — its f16 image does not fit an XCD's L2 — the other three on f16 images)
+    assert fam == ({"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}), fam
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
@@ -927,7 +928,7 @@ def test_full_size_batch_properties_mpnet_dims(make_model, q4, monkeypatch):
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention"} <= set(rep), sorted(rep)
     fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
-    assert fam == {"family:gemm256_q4" if q4 == "fused" else "family:gemm256_f16": 4 * hp.n_layer}, fam
+    assert fam == ({"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}), fam
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
