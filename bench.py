@@ -400,8 +400,28 @@ def latency_b1(tmpdir, calls=200):
             out[f"{ftype}_n{n}"] = {"median_us": float(np.median(ts)), "p10_us": float(np.percentile(ts, 10)), "p90_us": float(np.percentile(ts, 90)),
                                     "calls": calls, "launches": int(sum(v["launches"] for k, v in rep.items() if not k.startswith("family:")) // 5),
                                     "kernel_us": {k: round(1e3 * v["total_ms"] / 5, 1) for k, v in sorted(rep.items()) if not k.startswith("family:")}}
+        if ftype == "f16":
+            # the small batches of a polling server (reference examples/server.cpp answers one client at a time; this library's
+            # server evaluates a poll round as one call): 8 / 16 sentences of ~25 tokens, 4 of 128 — calls of up to 768 tokens
+            # take the latency route too (same bits as the batch route)
+            rng = np.random.default_rng(8)
+            for B, n in ((8, 25), (16, 25), (4, 128)):
+                lens = np.full(B, n) if n == 128 else np.clip(np.round(rng.lognormal(np.log(21.0), 0.55, B)), 3, 128).astype(np.int32)
+                cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+                ids = rng.integers(1000, hp.n_vocab, size=int(cu[-1])).astype(np.int32)
+                buf = np.empty((B, hp.n_embd), dtype=np.float32)
+                for _ in range(10):
+                    m.eval_packed(ids, cu, out=buf)
+                ts = []
+                for _ in range(calls):
+                    t0 = time.perf_counter()
+                    m.eval_packed(ids, cu, out=buf)
+                    ts.append(time.perf_counter() - t0)
+                ts = np.asarray(ts) * 1e6
+                out[f"{ftype}_b{B}_n{n}"] = {"median_us": float(np.median(ts)), "p10_us": float(np.percentile(ts, 10)), "p90_us": float(np.percentile(ts, 90)),
+                                            "calls": calls, "sentences": B, "tokens": int(cu[-1])}
         m.close()
-    out["entry"] = "bert_hip_eval_packed, n_sentences = 1, all-MiniLM-L6-v2 dims (host ids -> host embedding, blocking)"
+    out["entry"] = "bert_hip_eval_packed, n_sentences = 1 (and small batches b<B>_n<tokens>), all-MiniLM-L6-v2 dims (host ids -> host embeddings, blocking)"
     return out
 
 

@@ -114,7 +114,7 @@ private:
         // ONE pinned staging block per chunk — ids | cu_seqlens | windows, each part 16-byte aligned — and one device image of
         // it: a single H2D copy per chunk.  The embeddings come back without a copy: the pooling kernel writes them straight
         // into h_out (pinned, mapped into the device's address space as d_out_host).
-        char *h_in = nullptr;
+        char *h_in = nullptr, *d_in_host = nullptr;          // (d_in_host: h_in as the device sees it)
         float *h_out = nullptr, *d_out_host = nullptr;
         size_t h_in_cap = 0, h_out_cap = 0;
         DevBuf d_in, d_out;
@@ -127,6 +127,11 @@ private:
     bool f32_exact_ = true;           // ... and takes it unless BERT_HIP_F32=f16 / set_option("f32", "f16")
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch
     int chunk_tokens_ = 262144;
+    // Calls of at most this many tokens take the latency route (skinny.hip).  A call of T tokens keeps ceil(T / 128) CUs busy on
+    // the fused kernels — 615-685 us for anything from 129 to 3000 tokens of all-MiniLM-L6-v2 — while the route's time grows with T
+    // from 220 us: 252 us at 172 tokens (8 sentences), 330 at 363 (16), 376 at 512, 527 at 716, 606 at 1024 (round 5, same bits).
+    int latency_tokens_ = 768;
+    bool stage_kernel_ = true;        // small staged blocks come in by a kernel that reads the mapped pinned block, not by the copy engine
 
     // profiling
     bool profiling_ = false;

@@ -222,7 +222,14 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
         else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false, e->one_launch_ = 0;
     }
-    if (const char *f = getenv("BERT_HIP_LATENCY")) e->latency_ = strcmp(f, "0") != 0;
+    // (the cap of the latency route: measured on H = 384; a window of an H = 128 model costs the fused kernels less than five
+    // launches cost the route, so such models keep the one-window cap)
+    if (mf.hp.n_embd < 256) e->latency_tokens_ = 128;
+    // BERT_HIP_LATENCY: 0 = no latency route; 1 = the default cap; n >= 32: calls of at most n tokens take it
+    if (const char *f = getenv("BERT_HIP_LATENCY")) {
+        e->latency_ = strcmp(f, "0") != 0;
+        if (atoi(f) >= 32) e->latency_tokens_ = atoi(f);
+    }
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     // f32 files: f32 arithmetic like the reference's (f32_route.hip) unless BERT_HIP_F32=f16 asks for f16 operands and the fused kernels
@@ -336,6 +343,8 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "gemm256") gemm256_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
+    else if (key == "stage_kernel") stage_kernel_ = value != "0";
+    else if (key == "latency_tokens") { const int v = atoi(value.c_str()); if (v >= 32) latency_tokens_ = v; }
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "f32") f32_exact_ = value != "f16";       // f32 files: "exact" (f32 arithmetic, default) | "f16" (f16 operands, fused kernels)
     else if (key == "chunk_tokens") { const int v = atoi(value.c_str()); if (v > 0) chunk_tokens_ = v; }
@@ -351,7 +360,7 @@ bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     const size_t H = hp_.n_embd, I = hp_.n_intermediate, tp = (size_t)t_pad;
     const size_t es = f32_file_ ? 4 : 2;                      // (f32 files: the f32 route's activations are f32)
     return x_.ensure(tp * H * es, err) && qkv_.ensure(tp * 3 * H * es, err) && ctx_.ensure(tp * H * es, err) &&
-           y_.ensure(tp * H * es, err) && ff_.ensure(tp * I * es, err) && v32_.ensure((size_t)128 * H * 4, err) &&
+           y_.ensure(tp * H * es, err) && ff_.ensure(tp * I * es, err) && v32_.ensure((size_t)std::max(128, std::min(t_pad, (latency_tokens_ + 255) / 256 * 256)) * H * 4, err) &&
            d_out_.ensure((size_t)n_sentences * H * 4, err) &&
            windows_.ensure((size_t)n_sentences * sizeof(int2), err);
 }
@@ -486,7 +495,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const bool fused_windows = qkv2_ && !gemm_naive_ && !attn_naive_ && layers_[0]->qkv.mfma_ok && qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
     // all layers in one launch (model_kernel.hip): a workgroup carries its window through every layer
     // (every layer's matrices are checked: a file may mix types or shapes from layer to layer, and the kernel takes all layers' pointers)
-    bool one_launch_ok = fused_windows && one_launch_ && tail_ && !d_hidden && !(latency_ && T <= 128);
+    bool one_launch_ok = fused_windows && one_launch_ && tail_ && !d_hidden && !(latency_ && T <= latency_tokens_);
     for (int il = 0; one_launch_ok && il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
         one_launch_ok = L.qkv.mfma_ok && L.o.mfma_ok && L.ffi.mfma_ok && L.ffo.mfma_ok && L.ffi.w.w16p && L.ffo.w.w16p &&
@@ -518,7 +527,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     }
     // The latency route (skinny.hip): at most 128 tokens = one window of the fused kernels, which would keep one CU of 256 busy
     // per launch.  Same bits per sentence (the route must not show in the results), seven short launches per layer.
-    const bool skinny = latency_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && T <= 128 && max_len <= 128 && (dh == 32 || dh == 64) &&
+    const bool skinny = latency_ && tail_ && qkv2_ && !gemm_naive_ && !attn_naive_ && T <= latency_tokens_ && max_len <= 128 && (dh == 32 || dh == 64) &&
                         skinny_layer_supported(layers_[0]->qkv.w, layers_[0]->o.w, layers_[0]->ffi.w, layers_[0]->ffo.w) &&
                         qkv_attention2_supported(layers_[0]->qkv.w, nh, dh, max_len);
     if (skinny) {
@@ -677,12 +686,15 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     const size_t in_bytes = pad16(max_T * 4) + pad16((max_nb + 1) * 4) + pad16(max_nb * sizeof(int2));
     for (int i = 0; i < n_slots; ++i) {
         HostSlot &sl = slot_[i];
-        if (!ensure_pinned((void **)&sl.h_in, &sl.h_in_cap, in_bytes, err)) return -1;
+        const size_t in_cap = sl.h_in_cap;
+        // (16 spare bytes: the staging kernel copies whole 16-byte units)
+        if (!ensure_pinned((void **)&sl.h_in, &sl.h_in_cap, in_bytes + 16, err)) return -1;
+        if (sl.h_in_cap != in_cap || !sl.d_in_host) HIP_OK(hipHostGetDevicePointer((void **)&sl.d_in_host, sl.h_in, 0), err, -1);
         const size_t out_cap = sl.h_out_cap;
         if (!ensure_pinned((void **)&sl.h_out, &sl.h_out_cap, max_nb * H * 4, err)) return -1;
         if (sl.h_out_cap != out_cap || !sl.d_out_host)
             HIP_OK(hipHostGetDevicePointer((void **)&sl.d_out_host, sl.h_out, 0), err, -1);
-        if (!sl.d_in.ensure(in_bytes, err) || (d_embeddings && !sl.d_out.ensure(max_nb * H * 4, err))) return -1;
+        if (!sl.d_in.ensure(in_bytes + 16, err) || (d_embeddings && !sl.d_out.ensure(max_nb * H * 4, err))) return -1;
         if (!sl.done) HIP_OK(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming), err, -1);
     }
     if (!ensure_workspace((int)((max_T + 255) / 256 * 256), (int)max_nb, err)) return -1;
@@ -710,7 +722,11 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
             n_windows = (int)windows.size();
             memcpy(sl.h_in + off_w, windows.data(), windows.size() * sizeof(int2));
         }
-        if (hipMemcpyAsync(sl.d_in.p, sl.h_in, off_w + (size_t)n_windows * sizeof(int2), hipMemcpyHostToDevice, stream_) != hipSuccess) {
+        const size_t staged = off_w + (size_t)n_windows * sizeof(int2);
+        if (stage_kernel_ && staged <= ((size_t)2 << 20)) {
+            // (a small block: a few workgroups read it across the host link — the copy engine's start-up is ~20 us of a 0.8 ms call)
+            launch_stage_copy(sl.d_in_host, sl.d_in.p, staged, stream_);
+        } else if (hipMemcpyAsync(sl.d_in.p, sl.h_in, staged, hipMemcpyHostToDevice, stream_) != hipSuccess) {
             err = "hipMemcpyAsync (ids) failed";
             return fail();
         }

@@ -313,6 +313,9 @@ void launch_f32_layernorm(float *x, const float *gamma, const float *beta, int T
 void launch_f32_pool_normalize(const float *x, const int32_t *cu_seqlens, int n_sentences, int H, int max_len, int *status, float *out,
                                hipStream_t stream);
 
+// bytes (rounded up to 16) from mapped pinned host memory to device memory by a kernel (small staged blocks of the host API)
+void launch_stage_copy(const void *mapped_src, void *dst, size_t bytes, hipStream_t stream);
+
 // f16 [rows][cols] -> f32 (hidden-state tap)
 void launch_f16_to_f32(const half_t *src, float *dst, size_t n, hipStream_t stream);
 

@@ -2,6 +2,8 @@
 // LayerNorm, stand-alone LayerNorm, mean-pool + L2 normalise.  One 64-lane wavefront per token row
 // with __shfl_xor reductions; no LDS needed.
 #include "kernels.h"
+
+#include <algorithm>
 #include "pool_normalize.h"
 
 namespace bert_hip {
@@ -356,6 +358,19 @@ void launch_pool_normalize(const half_t *x, const int32_t *cu_seqlens, int n_sen
     if (n_sentences <= 0) return;
     BERT_LAUNCH(pool_normalize_kernel, dim3(n_sentences), dim3(256), (4 * H + 4) * sizeof(float), stream, x,
                        cu_seqlens, H, max_len, status, out);
+}
+
+// A call's staged block (ids | cu_seqlens | windows) from MAPPED pinned host memory into device memory by a kernel: the copy
+// engine needs about 20 us before the first kernel behind it can start, a few workgroups reading 16 bytes per lane across the host
+// link need 5-8 for the 130 KB of a 256 x 128 batch (engine.hip eval_packed_host; small blocks only).
+__global__ __launch_bounds__(256) void stage_copy_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+void launch_stage_copy(const void *mapped_src, void *dst, size_t bytes, hipStream_t stream) {
+    const int n16 = (int)((bytes + 15) / 16);
+    if (n16 <= 0) return;
+    BERT_LAUNCH(stage_copy_kernel, dim3(std::min(64, (n16 + 255) / 256)), dim3(256), 0, stream, (const uint4 *)mapped_src, (uint4 *)dst, n16);
 }
 
 __global__ void f16_to_f32_kernel(const half_t *src, float *dst, size_t n) {

@@ -111,16 +111,17 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
  *                          at load, or stay 4-bit in HBM and are dequantised in the tile loads of the same kernels (same values,
  *                          same bits on the fused kernels; a quarter of the weight bytes)
- *   BERT_HIP_LATENCY       1 (default) | 0 — batches of at most 128 tokens (one sentence per call, the reference's callers) take the
- *                          latency route: every mat-mul of a layer split over up to 192 workgroups (skinny.hip); same bits
- *                          (220 us per 128-token sentence, host to host)
+ *   BERT_HIP_LATENCY       1 (default) | 0 | n — calls of at most n tokens (default 768: one sentence per call, the reference's callers,
+ *                          and the small batches of a polling server) take the latency route: every mat-mul of a layer split by
+ *                          output features and token blocks over many workgroups (skinny.hip); same bits as the batch route
+ *                          (220 us per 128-token sentence, 330 us for 16 sentences of 25 tokens, host to host)
  *   BERT_HIP_F32           "exact" (default) | "f16" — f32 model files run in f32 arithmetic like the reference's (f32 activations,
  *                          v_mfma_f32_32x32x2_f32: f32_route.hip), or with their matrices rounded to f16 through the f16 kernels
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
- * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "chunk_tokens" = n, "profile_replay" (above).                                       */
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "chunk_tokens" = n, "profile_replay" (above).                                       */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);

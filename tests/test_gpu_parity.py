@@ -748,6 +748,22 @@ def test_latency_route_gives_the_batch_route_s_bits(make_model, dims, ftype):
         assert np.array_equal(few[k], batch[i]), (ftype, "few", lens[i])
     want = orc.Oracle(path).eval(sents[3])
     assert cosine(alone[3], want) >= TIGHT_COS_GGML[ftype]
+    # the shipped cap (768 tokens: small batches of a polling server): the 619-token batch itself on the route, and batches
+    # around the cap on either side
+    m.set_option("latency_tokens", "768")
+    m.profile(True)
+    routed = m.eval_batch(sents)
+    names = set(m.profile_report())
+    assert {"skinny_qkv", "skinny_ffn_down", "attention"} <= names and "layer_tail" not in names and "model_kernel" not in names, names
+    assert np.array_equal(routed, batch)
+    more = sents + sents[:3]                                  # 619 + 154 = 773 tokens: one token past the cap -> the batch route
+    out = m.eval_batch(more)
+    names = set(m.profile_report())
+    m.profile(False)
+    assert not any(k.startswith("skinny") for k in names), names
+    assert np.array_equal(out[:len(sents)], batch) and np.array_equal(out[len(sents):], batch[:3])
+    six = [sents[0]] * 6                                      # 768 tokens of full windows: still the route (not the one-launch kernel)
+    assert np.array_equal(m.eval_batch(six), np.stack([batch[0]] * 6))
 
 
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])

@@ -93,4 +93,4 @@ if enc:
 lat = bench["also"].get("latency_b1", {})
 for k, v in lat.items():
     if isinstance(v, dict):
-        print(f"latency {k:10s} median {v['median_us']:7.1f} us (p10 {v['p10_us']:.1f}, p90 {v['p90_us']:.1f}), {v['launches']} launches, kernels {v['kernel_us']}")
+        print(f"latency {k:12s} median {v['median_us']:7.1f} us (p10 {v['p10_us']:.1f}, p90 {v['p90_us']:.1f})", f"{v['launches']} launches, kernels {v['kernel_us']}" if "launches" in v else f"{v['sentences']} sentences, {v['tokens']} tokens")
