@@ -666,6 +666,6 @@ void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *valu
     });
 }
 
-const char *bert_hip_version(void) { return "bert.cpp_amd 0.2 (gfx950)"; }
+const char *bert_hip_version(void) { return "bert.cpp_amd 0.5 (gfx950)"; }
 
 }  // extern "C"
