@@ -110,7 +110,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
     // EVERY load of a thread is in flight before its first LDS store (one HBM round trip per loop iteration — the rolled
     // form — was most of the kernel's time at 512 tokens).
     constexpr int CPR = D / 8;                         // 16-byte chunks per row
-    constexpr int UNR = 4;                             // row pairs in flight per thread: 16 loads of 16 bytes
+    constexpr int UNR = MULTI ? 4 : 2;                 // row pairs in flight per thread: 16 (8) loads of 16 bytes
     uint4 kv[UNR][2], vv[UNR][2];
     auto request = [&](const Item &it, int base) __attribute__((always_inline)) {
         const int total = ((it.n + ATT_CHUNK - 1) / ATT_CHUNK * ATT_CHUNK / 2) * CPR;
@@ -193,10 +193,12 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
     // registers and ran 11.4 against 8.4 ms per 12 launches at 512 tokens; the 4-wave form of short sentences lost its third wave.)
     for (int qb = wave; qb < n_qblocks; qb += NT / 64) {
         f32x16 o[D / 32];
+        if constexpr (MULTI) {                         // (the short form's single chunk starts its P·V MFMAs from the constant 0)
 #pragma unroll
-        for (int dv = 0; dv < D / 32; ++dv)
+            for (int dv = 0; dv < D / 32; ++dv)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dv][r] = 0.f;
+                for (int r = 0; r < 16; ++r) o[dv][r] = 0.f;
+        }
         float m_run = -INFINITY, l_run = 0.f;
 
         // fragment addresses of the chunk at kc = 0: the swizzle of a K row depends on the row's low bits, i.e. on l31 only,
@@ -263,6 +265,36 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
             // numerators (softmax_p8, kernels.h; the same function in qkv_attention2.hip: equal bits across the kernels)
             float psum = 0.f;
+            if constexpr (!MULTI) {
+                // the short-sentence form is ONE chunk: all numerators first (the scores' 64 registers die into 32 of packed P), then
+                // P·V into accumulators that start from the constant 0 (= 0 x alpha) instead of registers zeroed before S^T and kept
+                // alive through it — 92 / 114 registers (d_head 32 / 64) instead of 110 / 148: four workgroups per CU where the d_head 64 form had three
+                // (same arithmetic in the same order: the same bits)
+                f16x8 pfr[KT][2];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+                        pfr[kt][st] = softmax_p8(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
+                                                 s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new, psum);
+                psum += __shfl_xor(psum, 32);
+                l_run = l_run * alpha + psum;
+                m_run = m_new;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int dv = 0; dv < D / 32; ++dv) {
+                            const lds_halfs vr = vbase[dv] + kt * 32 + 16 * st;
+                            const f16x4 v0 = *(const __attribute__((address_space(3))) f16x4 *)vr, v1 = *(const __attribute__((address_space(3))) f16x4 *)(vr + 8);
+                            f16x8 vf;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { vf[e] = v0[e]; vf[4 + e] = v1[e]; }
+                            o[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pfr[kt][st], kt == 0 && st == 0 ? (f32x16)0.f : o[dv], 0, 0, 0);
+                        }
+            } else {
             f16x8 pfr[KT][2];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
@@ -295,6 +327,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                         o[dv] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dv], 0, 0, 0);
                     }
                 }
+            }
 #pragma unroll
             for (int dv = 0; dv < D / 32; ++dv) vbase[dv] += CH;
             ATT_TL(asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1])); ATT_MARK(3) asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1]));)
