@@ -86,6 +86,10 @@ CONFIGS = {
             ftype="f16", batch=16384, seq_len=None, key="mixed_len"),
     55: dict(name="all-MiniLM-L6-v2 f16, 16384 sentences of mixed length (log-normal, mean ~25 tokens, 3..128), host API", dims="minilm-l6",
              ftype="f16", batch=16384, seq_len=None, key="mixed_len_host_api", host_step=True),
+    # the same batch with the opt-in 8-slot places of the attention windows (BERT_HIP_WINDOW_SLOTS=8: fewer windows; a sentence's last
+    # bits then depend on its place in its window, which is why it is not the default — DESIGN.md section 3)
+    58: dict(name="all-MiniLM-L6-v2 f16, 16384 sentences of mixed length (mean ~25 tokens), BERT_HIP_WINDOW_SLOTS=8 (opt-in)", dims="minilm-l6",
+             ftype="f16", batch=16384, seq_len=None, key="mixed_len_slots8", option=("window_slots", "8"), seed_id=5),
 }
 
 
@@ -152,6 +156,8 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     if not os.path.exists(path):
         gf.make_synthetic_model(path, cfg["dims"], cfg["ftype"], seed=0)
     model = load_model(cfg, path)
+    if cfg.get("option"):
+        model.set_option(*cfg["option"])
     B, H = cfg["batch"], hp.n_embd
     flat, cu, max_len = config_inputs(cfg, cfg_id, hp, rank)
     T = int(cu[-1])
@@ -744,7 +750,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=5, help="timed regions of --steps steps each; value = the median region")
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--also", type=int, nargs="*", default=None,
-                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 33, 4, 42, 44, 45, 5, 55)")
+                    help="extra configs reported under 'also' (default at N=1 with config 1: 2, 22, 3, 33, 4, 42, 44, 45, 5, 55, 58)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inproc", action="store_true", help="one process, --gpus N devices inside libbert.so")
     args = ap.parse_args()
@@ -803,7 +809,7 @@ def main():
         else:
             kernel_roofline(res, torch, device, steps=int(min(20, max(2, 0.4 / (res["ms_per_step"] * 1e-3)))), groups=3)      # (the same passes as rank 0's report: the steps hold collectives)
         res["model"].close()
-        also = args.also if args.also is not None else ([2, 22, 3, 33, 4, 42, 44, 45, 5, 55] if world == 1 and args.config == 1 else [])
+        also = args.also if args.also is not None else ([2, 22, 3, 33, 4, 42, 44, 45, 5, 55, 58] if world == 1 and args.config == 1 else [])
         extras = {}
         for cid in also:
             big = CONFIGS[cid]["dims"] in ("bert-base", "mpnet-dims")
@@ -817,12 +823,21 @@ def main():
                     extras[key] = report(r2, world, torch, device, args, prof_steps=2 if big else 3, cpu_budget=2.5 if big else 2.0)
                 else:
                     kernel_roofline(r2, torch, device, steps=2 if big else 3)
+                if CONFIGS[cid].get("option", ("", ""))[0] == "window_slots":
+                    r2["model"].set_option("window_slots", "16")          # (the setting is process-wide)
                 r2["model"].close()
             except (Exception, SystemExit) as ex:                      # an auxiliary entry must never cost the headline line (its error is in the line and on stderr)
                 if world > 1:
                     raise
                 extras[key] = {"workload": CONFIGS[cid]["name"], "error": f"{type(ex).__name__}: {ex}"}
                 print(f"bench.py: entry {key} failed: {ex}", file=sys.stderr)
+                if CONFIGS[cid].get("option", ("", ""))[0] == "window_slots":        # (process-wide: back to the default whatever happened)
+                    try:
+                        m2 = pybert.BertModel(os.path.join(tmpdir, f"minilm-l6_f16_rank{rank}.bin"))
+                        m2.set_option("window_slots", "16")
+                        m2.close()
+                    except Exception:
+                        pass
             clock(key)
         if rank == 0:
             if world == 1 and args.config == 1 and args.also is None:

@@ -232,6 +232,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
     }
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
+    if (const char *c = getenv("BERT_HIP_WINDOW_SLOTS")) set_window_slots(atoi(c));
     // f32 files: f32 arithmetic like the reference's (f32_route.hip) unless BERT_HIP_F32=f16 asks for f16 operands and the fused kernels
     if (const char *f = getenv("BERT_HIP_F32")) e->f32_exact_ = strcmp(f, "f16") != 0;
     if (mf.hp.n_embd % 2 != 0) { err = "n_embd must be even"; delete e; return nullptr; }
@@ -344,6 +345,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "stage_kernel") stage_kernel_ = value != "0";
+    else if (key == "window_slots") set_window_slots(atoi(value.c_str()));      // (process-wide: 16, or 8 — see kernels.h)
     else if (key == "latency_tokens") { const int v = atoi(value.c_str()); if (v >= 32) latency_tokens_ = v; }
     else if (key == "one_launch") one_launch_ = value == "0" ? 0 : value == "2" ? 2 : 1;
     else if (key == "f32") f32_exact_ = value != "f16";       // f32 files: "exact" (f32 arithmetic, default) | "f16" (f16 operands, fused kernels)
@@ -437,6 +439,7 @@ std::string Engine::profile_report() {
 
 void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows) {
     windows.clear();
+    const int slot = window_slots();                          // 16 (or 8: kernels.h)
     int first = 0, fill = 0;                                  // open window: sentences first .. b-1 occupy `fill` slots
     for (int b = 0; b < B; ++b) {
         const int n = cu[b + 1] - cu[b];
@@ -444,7 +447,7 @@ void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows)
             windows.push_back(make_int2(first, b - first));
             first = b; fill = 0;
         }
-        fill = (fill + n + 15) & ~15;
+        fill = (fill + n + slot - 1) & ~(slot - 1);
     }
     if (B > first) windows.push_back(make_int2(first, B - first));
 }
@@ -506,7 +509,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         const int spw = qkv_attention2_sentences_per_window(max_len), uniform = (B + spw - 1) / spw;
         // (forced one-launch: the kernel takes a window list or one sentence per window — its layer-tail phase needs a window's
         // tokens to be at most 128 whatever the sentences' lengths turn out to be)
-        if (4ll * uniform * 128 > 5 * ((long long)T + 8ll * B) || (one_launch_ok && one_launch_ == 2 && spw > 1 && !full_windows)) {
+        if (4ll * uniform * 128 > 5 * ((long long)T + (long long)(window_slots() / 2) * B) || (one_launch_ok && one_launch_ == 2 && spw > 1 && !full_windows)) {
             int *count = status_.as<int>() + 1;
             timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, s); });
             d_windows = windows_.as<int2>();

@@ -251,6 +251,9 @@ void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float 
 // next-fit windows (the rule of Engine::build_windows) computed on the device from cu_seqlens; *n_windows receives their number
 void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream);
 int qkv_attention2_max_windows(int n_sentences, int n_tokens);
+// place granularity of the windows (16, or 8: qkv_attention2.hip), process-wide
+int window_slots();
+void set_window_slots(int slots);
 
 // mean over the sentence's tokens, then L2 normalise; out f32 [n_sentences][H].  A sentence whose length is not in
 // [1, max_len] (the caller of the device API promised max_len) gets a NaN row and sets *status (device word) to 1.

@@ -52,7 +52,7 @@ struct ModelArgs {
     const int32_t *cu;
     const int2 *groups;              // RAGGED: per window {first sentence, count} (qkv_attention2.hip), or nullptr: one sentence per window
     const int *n_groups;             // RAGGED: device word holding the number of windows (the grid is an upper bound), or nullptr
-    int n_layer, n_head, n_sent, I;
+    int n_layer, n_head, n_sent, I, slot_mask;      // slot_mask: the windows' place granularity - 1 (Qkv2Args)
     float *pooled;                   // [n_sent][H] f32: the sentences' pooled, normalised rows (the workgroup pools its window itself), or nullptr
     int *status;                     // pooling's status word (a sentence outside [1, max_len])
     int max_len;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(512, 2) void model_kernel(ModelArgs m) {
         {
             Qkv2Args q;
             q.x = m.x; q.w = L.wqkv; q.qs = nullptr; q.sc = nullptr; q.bias = L.bqkv; q.cu = m.cu; q.groups = RAGGED ? m.groups : nullptr; q.n_groups = nullptr;
-            q.out = m.ctx; q.n_head = m.n_head; q.n_sent = m.n_sent; q.spw = 1;
+            q.out = m.ctx; q.n_head = m.n_head; q.n_sent = m.n_sent; q.spw = 1; q.slot_mask = m.slot_mask;
             qkv_attention2_body<2 * NT, NT, GW_F16>(q, smem, window, tid);
         }
         // ctx is written (attention waves), every LDS access of the phase has returned: hand over to the tail
@@ -152,7 +152,7 @@ void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x
     ModelArgs m;
     m.pooled = pooled; m.status = status; m.max_len = max_len;
     m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.groups = groups; m.n_groups = n_groups_dev;
-    m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N;
+    m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N; m.slot_mask = window_slots() - 1;
     for (int l = 0; l < n_layer; ++l) {
         const ModelLayerWeights &s = layers[l];
         ModelLayerArgs &d = m.layer[l];

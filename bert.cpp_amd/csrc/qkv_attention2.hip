@@ -58,6 +58,7 @@ struct Qkv2Args {
     const int *n_groups;     // device word holding the number of windows (device-built windows: the grid is an upper bound), or nullptr
     half_t *out;             // [T_pad][H] attention context
     int n_head, n_sent, spw;
+    int slot_mask;           // sentence places in a window start at multiples of slot_mask + 1 slots (15; 7 with BERT_HIP_WINDOW_SLOTS=8)
 };
 
 __device__ __forceinline__ int q2_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -174,7 +175,7 @@ __device__ __forceinline__ void qkv_attention2_body(const Qkv2Args &a, char *sme
         for (int j = 0; j < count; ++j) {
             const int t0 = a.cu[first + j], n = min(a.cu[first + j + 1] - t0, place);
             if (slot >= off && slot < off + n) { gtok = t0 + slot - off; k0 = off; k1 = off + n; }
-            off = (off + n + 15) & ~15;
+            off = (off + n + a.slot_mask) & ~a.slot_mask;
         }
     }
 
@@ -553,11 +554,14 @@ __global__ __launch_bounds__(512, 2) void qkv_attention2_kernel(Qkv2Args a) {
 // ALL nine entry states at once and records where each ends up, how many windows it closes and which sentence opened the
 // window it leaves open; thread 0 chains the per-block maps; every thread then replays its block from its true entry state
 // and writes the windows it closes.
-constexpr int BW_THREADS = 512, BW_STATES = 9;
+constexpr int BW_THREADS = 512;
 
+// SLOT: the place granularity (16; 8 with BERT_HIP_WINDOW_SLOTS=8): 128 / SLOT + 1 fill states
+template <int SLOT>
 __global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t *__restrict__ cu, int B, int2 *__restrict__ windows,
                                                                    int *__restrict__ n_windows) {
-    __shared__ unsigned char exit_state[BW_THREADS][BW_STATES];   // fill / 16 after the block
+    constexpr int BW_STATES = 128 / SLOT + 1;
+    __shared__ unsigned char exit_state[BW_THREADS][BW_STATES];   // fill / SLOT after the block
     __shared__ int closes[BW_THREADS][BW_STATES];                 // windows closed inside the block
     __shared__ int opened[BW_THREADS][BW_STATES];                 // first sentence of the window left open; -1: the entry window
     __shared__ int entry_fill[BW_THREADS], entry_first[BW_THREADS], entry_index[BW_THREADS];
@@ -566,25 +570,25 @@ __global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t
 
     int fill[BW_STATES], n_closed[BW_STATES], first[BW_STATES];
 #pragma unroll
-    for (int e = 0; e < BW_STATES; ++e) { fill[e] = e * 16; n_closed[e] = 0; first[e] = -1; }
+    for (int e = 0; e < BW_STATES; ++e) { fill[e] = e * SLOT; n_closed[e] = 0; first[e] = -1; }
     for (int b = b0; b < b1; ++b) {
         const int n = cu[b + 1] - cu[b];
 #pragma unroll
         for (int e = 0; e < BW_STATES; ++e) {
             if (fill[e] == 0) first[e] = b;                       // an empty window opens at this sentence
             else if (fill[e] + n > 128) { ++n_closed[e]; first[e] = b; fill[e] = 0; }
-            fill[e] = min(128, (fill[e] + n + 15) & ~15);         // (no sentence is longer than a window here)
+            fill[e] = min(128, (fill[e] + n + SLOT - 1) & ~(SLOT - 1));         // (no sentence is longer than a window here)
         }
     }
 #pragma unroll
     for (int e = 0; e < BW_STATES; ++e) {
-        exit_state[t][e] = (unsigned char)(fill[e] / 16); closes[t][e] = n_closed[e]; opened[t][e] = first[e];
+        exit_state[t][e] = (unsigned char)(fill[e] / SLOT); closes[t][e] = n_closed[e]; opened[t][e] = first[e];
     }
     __syncthreads();
     if (t == 0) {
         int e = 0, open_first = 0, index = 0;
         for (int k = 0; k < n_blocks; ++k) {
-            entry_fill[k] = e * 16; entry_first[k] = open_first; entry_index[k] = index;
+            entry_fill[k] = e * SLOT; entry_first[k] = open_first; entry_index[k] = index;
             index += closes[k][e];
             if (opened[k][e] >= 0) open_first = opened[k][e];
             e = exit_state[k][e];
@@ -599,18 +603,26 @@ __global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t
             const int n = cu[b + 1] - cu[b];
             if (f == 0) open_first = b;
             else if (f + n > 128) { windows[index++] = make_int2(open_first, b - open_first); open_first = b; f = 0; }
-            f = min(128, (f + n + 15) & ~15);
+            f = min(128, (f + n + SLOT - 1) & ~(SLOT - 1));
         }
     }
 }
 
+// The place granularity of the windows, process-wide (BERT_HIP_WINDOW_SLOTS / bert_hip_set_option "window_slots"): 16 — one k-step
+// of the P·V MFMAs, so that a sentence's bits do not depend on where it sits in a window — or 8: a quarter fewer windows for
+// mean-25-token batches, and bits that depend on a sentence's place (tools/ubench/mfma_shift.hip).
+static std::atomic<int> g_window_slots{16};
+int window_slots() { return g_window_slots.load(std::memory_order_relaxed); }
+void set_window_slots(int slots) { g_window_slots.store(slots == 8 ? 8 : 16, std::memory_order_relaxed); }
+
 void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream) {
-    BERT_LAUNCH(build_windows_kernel, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
+    if (window_slots() == 8) BERT_LAUNCH(build_windows_kernel<8>, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
+    else BERT_LAUNCH(build_windows_kernel<16>, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
 }
 
 int qkv_attention2_max_windows(int n_sentences, int n_tokens) {
     // two consecutive next-fit windows hold more than 128 slots together
-    const long long slots = (long long)n_tokens + 15ll * n_sentences;
+    const long long slots = (long long)n_tokens + (long long)(window_slots() - 1) * n_sentences;
     const long long bound = 2 * (slots / 128) + 2;
     return (int)(bound < n_sentences ? bound : n_sentences);
 }
@@ -621,14 +633,14 @@ bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, in
            max_len <= Q2_WIN && max_len > 0;
 }
 
-int qkv_attention2_sentences_per_window(int max_len) { return Q2_WIN / ((max_len + 15) & ~15); }
+int qkv_attention2_sentences_per_window(int max_len) { const int m = window_slots() - 1; return Q2_WIN / ((max_len + m) & ~m); }
 
 void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
                            int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
                            half_t *out, hipStream_t stream) {
     Qkv2Args a;
     a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.n_groups = n_groups_dev; a.out = out;
-    a.n_head = n_head; a.n_sent = n_sentences;
+    a.n_head = n_head; a.n_sent = n_sentences; a.slot_mask = window_slots() - 1;
     a.spw = qkv_attention2_sentences_per_window(max_len);
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;

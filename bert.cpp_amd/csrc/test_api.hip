@@ -255,6 +255,8 @@ int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t n_sentenc
 
 int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens) { return qkv_attention2_max_windows(n_sentences, n_tokens); }
 
+int32_t bert_hip_test_set_window_slots(int32_t slots) { set_window_slots(slots); return window_slots(); }
+
 int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows) {
     std::string err;
     DevBuf dcu, dwin, dcount;

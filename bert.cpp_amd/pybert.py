@@ -30,7 +30,7 @@ BERT_HIP_H_SYMBOLS = [
 BERT_HIP_TEST_H_SYMBOLS = [
     "bert_hip_test_gemm", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
-    "bert_hip_test_build_windows_device", "bert_hip_test_max_windows",
+    "bert_hip_test_build_windows_device", "bert_hip_test_max_windows", "bert_hip_test_set_window_slots",
     "bert_hip_test_dispatch", "bert_hip_test_shard_threads_created", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
     "bert_hip_test_model_digest",
 ]
@@ -125,6 +125,8 @@ def test_lib() -> C.CDLL:
     L.bert_hip_test_build_windows.argtypes = [i32p, i32, i32p]
     L.bert_hip_test_max_windows.restype = i32
     L.bert_hip_test_max_windows.argtypes = [i32, i32]
+    L.bert_hip_test_set_window_slots.restype = i32
+    L.bert_hip_test_set_window_slots.argtypes = [i32]
     L.bert_hip_test_build_windows_device.restype = i32
     L.bert_hip_test_build_windows_device.argtypes = [i32p, i32, i32p]
     L.bert_hip_test_shard_threads_created.restype = C.c_int64
@@ -184,6 +186,11 @@ def build_windows(cu_seqlens: np.ndarray, device: bool = False) -> List[tuple]:
     if n < 0:
         raise RuntimeError("bert_hip_test_build_windows_device failed")
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
+def set_window_slots(slots: int) -> int:
+    """Place granularity of the windows in libbert_test.so (its own copy of the setting; a context's: set_option "window_slots")."""
+    return int(test_lib().bert_hip_test_set_window_slots(slots))
 
 
 def max_windows(n_sentences: int, n_tokens: int) -> int:

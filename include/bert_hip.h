@@ -100,7 +100,7 @@ BERT_API int32_t bert_hip_eval_hidden(struct bert_ctx *ctx, const bert_vocab_id 
 BERT_API void    bert_hip_profile_enable(struct bert_ctx *ctx, int32_t on);
 BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_t buf_len);
 
-/* Environment, read by bert_load_from_file (seven switches):
+/* Environment, read by bert_load_from_file (eight switches):
  *   BERT_HIP_DEVICES       "all" or a comma-separated list of HIP ordinals without repeats: the GPUs of the context
  *                          (default: the calling thread's current device — one context, one GPU, unless asked otherwise);
  *                          BERT_HIP_DEVICE=<n>, the spelling of the first builds, is read as a list of one when this is unset
@@ -117,11 +117,16 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *                          (220 us per 128-token sentence, 330 us for 16 sentences of 25 tokens, host to host)
  *   BERT_HIP_F32           "exact" (default) | "f16" — f32 model files run in f32 arithmetic like the reference's (f32 activations,
  *                          v_mfma_f32_32x32x2_f32: f32_route.hip), or with their matrices rounded to f16 through the f16 kernels
+ *   BERT_HIP_WINDOW_SLOTS  16 (default) | 8 — PROCESS-WIDE: sentences start at multiples of this many slots inside the 128-slot windows of the
+ *                          fused attention kernels.  8 packs mean-25-token batches into about an eighth fewer windows; the price is
+ *                          that a sentence's embedding then depends, in its last bits, on where it sits in its window — 16 slots are
+ *                          one k-step of the P.V MFMAs, 8 are not (tools/ubench/mfma_shift.hip) — so "the same sentence gives the
+ *                          same bits in any batch" holds only with 16.  Cosines against the CPU are unchanged.
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
- * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "chunk_tokens" = n, "profile_replay" (above).                                       */
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "window_slots" = "16" | "8" (process-wide), "chunk_tokens" = n, "profile_replay" (above).                                       */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);

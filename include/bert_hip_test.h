@@ -66,6 +66,8 @@ BERT_API int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t 
 /* Upper bound of the number of windows used to size the grid of the fused attention kernel when the windows are built on the
  * device (a function of the sentence and token counts only).                                                             */
 BERT_API int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens);
+/* the windows' place granularity in THIS library (16, or 8: BERT_HIP_WINDOW_SLOTS / option "window_slots"); returns the value now in force */
+BERT_API int32_t bert_hip_test_set_window_slots(int32_t slots);
 /* The same windows from the device-side builder the asynchronous device API uses (needs a GPU; -1 on a HIP error).        */
 BERT_API int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows);
 /* The multi-device dispatcher (shards, a persistent worker thread per shard beyond the first, results straight into the

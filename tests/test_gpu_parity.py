@@ -304,11 +304,23 @@ def test_qkv_attention2_kernel_q4(n_head, lens, mode, wtype):
     assert np.abs(got.astype(np.float64) - split.astype(np.float64)).max() < 6e-3
 
 
+@pytest.mark.parametrize("slot", [16, 8])
 @pytest.mark.parametrize("n_sentences", [1, 2, 7, 511, 512, 513, 1024, 5000, 40000])
 @pytest.mark.parametrize("dist", ["short", "mixed", "full", "sixteens"])
-def test_windows_built_on_the_device_equal_the_host_builder(n_sentences, dist):
+def test_windows_built_on_the_device_equal_the_host_builder(n_sentences, dist, slot):
     """The device API packs sentences into 128-slot windows with a kernel (a scan over the next-fit automaton's nine
-    states, qkv_attention2.hip build_windows_kernel); the host path with a loop (engine.hip build_windows): same list."""
+    states — seventeen with 8-slot places —, qkv_attention2.hip build_windows_kernel); the host path with a loop (engine.hip
+    build_windows): same list."""
+    if slot == 8 and n_sentences in (2, 511, 513):
+        pytest.skip("8-slot places: a subset of the sizes")
+    pybert.set_window_slots(slot)
+    try:
+        _windows_equal(n_sentences, dist)
+    finally:
+        pybert.set_window_slots(16)
+
+
+def _windows_equal(n_sentences, dist):
     rng = np.random.default_rng(n_sentences * 7 + len(dist))
     lens = {"short": lambda: rng.integers(1, 20, n_sentences),
             "mixed": lambda: np.clip(rng.gamma(2.0, 14.0, n_sentences).astype(np.int64) + 1, 1, 128),
@@ -319,6 +331,41 @@ def test_windows_built_on_the_device_equal_the_host_builder(n_sentences, dist):
     dev = pybert.build_windows(cu, device=True)
     assert dev == host, (len(dev), len(host), next((i, a, b) for i, (a, b) in enumerate(zip(dev, host)) if a != b) if len(dev) == len(host) else None)
     assert sum(c for _, c in dev) == n_sentences
+
+
+def test_eight_slot_places_option(make_model):
+    """bert_hip_set_option "window_slots" = "8" (BERT_HIP_WINDOW_SLOTS): sentences start at multiples of 8 slots inside the
+    attention windows — fewer windows for short sentences.  What holds: the device-built window list equals the host's (test
+    above), embeddings agree with the oracle as before, batches whose lengths are all multiples of 16 keep the 16-slot form's
+    bits (every place is a multiple of 16 again).  What does NOT hold any more, and why the option is off by default: a
+    sentence's last bits depend on where it sits (v_mfma's sum over a 16-key step depends on the k-slot: tools/ubench/mfma_shift.hip)."""
+    path, hp = make_model("minilm-l6", "f16", 0)
+    m = pybert.BertModel(path)
+    rng = np.random.default_rng(21)
+    lens = np.clip(np.round(rng.lognormal(np.log(21.0), 0.55, 2000)), 3, 128).astype(np.int32)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    toks = rng.integers(1000, hp.n_vocab, size=int(cu[-1])).astype(np.int32)
+    lens16 = rng.choice([16, 32, 48, 64, 128], 1500).astype(np.int32)
+    cu16 = np.concatenate([[0], np.cumsum(lens16)]).astype(np.int32)
+    toks16 = rng.integers(1000, hp.n_vocab, size=int(cu16[-1])).astype(np.int32)
+    base, base16 = m.eval_packed(toks, cu), m.eval_packed(toks16, cu16)
+    try:
+        m.set_option("window_slots", "8")
+        m.profile(True)
+        got = m.eval_packed(toks, cu)
+        assert "qkv_attention2" in m.profile_report()
+        m.profile(False)
+        got16 = m.eval_packed(toks16, cu16)
+    finally:
+        m.set_option("window_slots", "16")
+    assert np.array_equal(got16, base16)                                  # places at multiples of 16 again: the same bits
+    cos = np.einsum("ij,ij->i", got, base)
+    assert cos.min() >= 1 - 1e-6 and np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-3
+    assert not np.array_equal(got, base)                                  # (the documented price: last bits move with the place)
+    o = orc.Oracle(path)
+    for i in (0, 7, 999, 1999):
+        assert cosine(got[i], o.eval(toks[cu[i]:cu[i + 1]], orc.MODE_GGML)) >= 1 - 1e-4
+    assert np.array_equal(m.eval_packed(toks, cu), base)                  # back at 16: the default's bits
 
 
 def test_qkv_attention2_same_bits_in_any_window():

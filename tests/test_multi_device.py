@@ -31,29 +31,46 @@ def test_shard_bounds_match_the_python_layer_and_balance_tokens():
     assert pybert.shard_bounds(cu[2:], 2) == [b - 0 for b in pybert.shard_bounds(_cu([100, 3, 64, 64, 7]), 2)]
 
 
-def test_windows_hold_whole_sentences_in_order_and_fit():
-    rng = np.random.default_rng(1)
-    for trial in range(50):
-        n = int(rng.integers(1, 300))
-        lens = np.clip(np.round(rng.lognormal(np.log(21.0), 0.7, n)), 1, 128).astype(int).tolist()
-        win = pybert.build_windows(_cu(lens))
-        assert win[0][0] == 0 and sum(c for _, c in win) == n
-        nxt = 0
-        for first, count in win:
-            assert first == nxt and count >= 1
-            nxt = first + count
-            fill = 0
-            for L in lens[first:first + count]:
-                assert fill + L <= 128                     # the sentence starts at a multiple of 16 and fits
-                fill = (fill + L + 15) // 16 * 16
-        # next-fit: a window is only closed when the next sentence does not fit
-        for (f0, c0), (f1, _) in zip(win, win[1:]):
-            fill = 0
-            for L in lens[f0:f0 + c0]:
-                fill = (fill + L + 15) // 16 * 16
-            assert fill + lens[f1] > 128
-    assert pybert.build_windows(_cu([128] * 5)) == [(i, 1) for i in range(5)]
-    assert pybert.build_windows(_cu([16] * 8 + [1])) == [(0, 8), (8, 1)]
+@pytest.mark.parametrize("slot", [16, 8])
+def test_windows_hold_whole_sentences_in_order_and_fit(slot):
+    """The host builder with 16-slot places (the default) and with 8-slot places (BERT_HIP_WINDOW_SLOTS=8: denser, but a
+    sentence's bits then depend on its place — DESIGN.md §3)."""
+    assert pybert.set_window_slots(slot) == slot
+    try:
+        rng = np.random.default_rng(1)
+        total = 0
+        for trial in range(50):
+            n = int(rng.integers(1, 300))
+            lens = np.clip(np.round(rng.lognormal(np.log(21.0), 0.7, n)), 1, 128).astype(int).tolist()
+            win = pybert.build_windows(_cu(lens))
+            total += len(win)
+            assert win[0][0] == 0 and sum(c for _, c in win) == n
+            nxt = 0
+            for first, count in win:
+                assert first == nxt and count >= 1
+                nxt = first + count
+                fill = 0
+                for L in lens[first:first + count]:
+                    assert fill + L <= 128                     # the sentence starts at a multiple of `slot` and fits
+                    fill = (fill + L + slot - 1) // slot * slot
+            # next-fit: a window is only closed when the next sentence does not fit
+            for (f0, c0), (f1, _) in zip(win, win[1:]):
+                fill = 0
+                for L in lens[f0:f0 + c0]:
+                    fill = (fill + L + slot - 1) // slot * slot
+                assert fill + lens[f1] > 128
+            assert len(win) <= pybert.max_windows(n, sum(lens)) <= n
+        assert pybert.build_windows(_cu([128] * 5)) == [(i, 1) for i in range(5)]
+        assert pybert.build_windows(_cu([16] * 8 + [1])) == [(0, 8), (8, 1)]
+        assert pybert.build_windows(_cu([8] * 17)) == ([(0, 16), (16, 1)] if slot == 8 else [(0, 8), (8, 8), (16, 1)])
+        _WINDOWS_BUILT[slot] = total
+        if len(_WINDOWS_BUILT) == 2:
+            assert _WINDOWS_BUILT[8] < 0.93 * _WINDOWS_BUILT[16]          # (mean ~25 tokens: an eighth fewer windows)
+    finally:
+        pybert.set_window_slots(16)
+
+
+_WINDOWS_BUILT = {}
 
 
 def test_the_grid_bound_of_device_built_windows_covers_every_packing():
