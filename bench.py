@@ -434,8 +434,8 @@ def latency_b1(tmpdir, calls=200):
 def encode_batch_rate(tmpdir, n_texts=32768, calls=5):
     """Strings in, embeddings out: bert_encode_batch (what the reference's ctypes callers use: sample_dylib.py:50-58,
     run_mteb.py:57-72) on English-like text of ~22 words per line (the length of the reference's sample_client_texts.txt lines)
-    with a WordPiece vocabulary built from the same text; the host tokenizes group g + 1 on `threads` threads while group g is
-    on the GPU.  texts/s, median of `calls` calls; the pointer arrays are built once outside the timed calls."""
+    with a WordPiece vocabulary built from the same text; the host tokenizes and packs group g + 1 on `threads` threads while group g is
+    on the GPU (groups of 2048, 4096, 8192, then 16384 texts).  texts/s, median of `calls` calls; the pointer arrays are built once outside the timed calls."""
     import collections
     import ctypes as C
     import random

@@ -9,6 +9,7 @@
 //   bert_params_parse    bert.cpp:140-193
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,6 +47,14 @@ struct bert_ctx {
     // them and kept: a group of 4096 texts tokenizes in about a millisecond, sixteen thread starts cost a third of that
     mutable std::unique_ptr<ShardWorkers> tok_workers;
     mutable int tok_workers_asked = 0;
+    // bert_encode_batch's two groups of tokenized texts (one on the GPU, one being tokenized): kept between calls, grown only,
+    // never zero-filled (the tokenizer writes what is read; 16384 texts x n_max_tokens ids are 32 MiB of pages to touch otherwise)
+    struct EncodeGroup {
+        std::unique_ptr<bert_vocab_id[]> ids, packed;      // [n][n_max_tokens] as tokenized; the same ids back to back
+        size_t ids_cap = 0, packed_cap = 0;
+        std::vector<int32_t> n_tokens, cu;
+        int32_t n_ok = 0;                                   // texts in front of the first one the engine cannot take (= all of them)
+    } enc_group[2];
     // test knobs (bert_hip_set_option "test_inject_bad_alloc" / "test_rccl_single"): the ABI's catch-all; the exchange step
     // through a 1-rank communicator on a single device
     bool inject_bad_alloc = false, rccl_single = false;
@@ -302,6 +311,31 @@ void bert_tokenize(struct bert_ctx *ctx, const char *text, bert_vocab_id *tokens
     guarded_void("bert_tokenize", [&] { ctx->tok.tokenize(text, tokens, n_tokens, n_max_tokens); });
 }
 
+// B validated sentences, packed, into the caller's rows: B, or -1 on a device error
+static int32_t eval_packed_rows(struct bert_ctx *ctx, const bert_vocab_id *packed, const int32_t *cu, int32_t B, float *const *batch_embeddings) {
+    const int H = ctx->hp.n_embd;
+    std::string err;
+    // the caller's rows are usually the rows of ONE matrix (NumPy rows through ctypes: reference examples/sample_dylib.py:50-51):
+    // then the engine writes them in place; scattered rows go through a matrix of our own.  (A device error half way through a
+    // call of several chunks leaves the rows of the finished chunks written in the first case, nothing in the second.)
+    bool rows_of_one_matrix = true;
+    for (int32_t b = 1; b < B && rows_of_one_matrix; ++b) rows_of_one_matrix = batch_embeddings[b] == batch_embeddings[0] + (size_t)b * H;
+    if (rows_of_one_matrix) {
+        if (eval_packed_all_devices(ctx, packed, cu, B, batch_embeddings[0], err) != 0) {
+            fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
+            return -1;
+        }
+        return B;
+    }
+    std::vector<float> out((size_t)B * H);
+    if (eval_packed_all_devices(ctx, packed, cu, B, out.data(), err) != 0) {
+        fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
+        return -1;
+    }
+    for (int32_t b = 0; b < B; ++b) memcpy(batch_embeddings[b], out.data() + (size_t)b * H, sizeof(float) * H);
+    return B;
+}
+
 // returns the number of sentences evaluated (stops in front of the first one it cannot handle), -1 on a device error
 static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_vocab_id *const *batch_tokens,
                                const int32_t *n_tokens, float *const *batch_embeddings) {
@@ -318,27 +352,7 @@ static int32_t eval_batch_impl(struct bert_ctx *ctx, int32_t n_batch_size, bert_
     for (int32_t b = 0; b < B; ++b) cu[b + 1] = cu[b] + n_tokens[b];
     std::vector<int32_t> packed((size_t)cu[B]);
     for (int32_t b = 0; b < B; ++b) memcpy(packed.data() + cu[b], batch_tokens[b], sizeof(int32_t) * n_tokens[b]);
-    const int H = ctx->hp.n_embd;
-    std::string err;
-    // the caller's rows are usually the rows of ONE matrix (NumPy rows through ctypes: reference examples/sample_dylib.py:50-51):
-    // then the engine writes them in place; scattered rows go through a matrix of our own.  (A device error half way through a
-    // call of several chunks leaves the rows of the finished chunks written in the first case, nothing in the second.)
-    bool rows_of_one_matrix = true;
-    for (int32_t b = 1; b < B && rows_of_one_matrix; ++b) rows_of_one_matrix = batch_embeddings[b] == batch_embeddings[0] + (size_t)b * H;
-    if (rows_of_one_matrix) {
-        if (eval_packed_all_devices(ctx, packed.data(), cu.data(), B, batch_embeddings[0], err) != 0) {
-            fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
-            return -1;
-        }
-        return B;
-    }
-    std::vector<float> out((size_t)B * H);
-    if (eval_packed_all_devices(ctx, packed.data(), cu.data(), B, out.data(), err) != 0) {
-        fprintf(stderr, "bert_eval_batch: %s\n", err.c_str());
-        return -1;
-    }
-    for (int32_t b = 0; b < B; ++b) memcpy(batch_embeddings[b], out.data() + (size_t)b * H, sizeof(float) * H);
-    return B;
+    return eval_packed_rows(ctx, packed.data(), cu.data(), B, batch_embeddings);
 }
 
 void bert_eval_batch(struct bert_ctx *ctx, int32_t /*n_threads*/, int32_t n_batch_size, bert_vocab_id **batch_tokens,
@@ -387,27 +401,50 @@ static void tokenize_many(const bert_ctx *ctx, int32_t n_threads, int32_t n_inpu
 static int32_t encode_batch_impl(struct bert_ctx *ctx, int32_t n_threads, int32_t n_inputs, const char **texts, float **embeddings) {
     if (n_inputs <= 0) return 0;
     const int32_t N = ctx->hp.n_max_tokens;
-    // Tokenize on n_threads host threads (at 10^5 sentences/s on the GPU the tokenizer is the stage in front of the
+    // Tokenize on n_threads host threads (at 10^6 sentences/s on the GPU the tokenizer is the stage in front of the
     // path that has to keep up) and evaluate as packed device batches (the reference sorts by length and loops with
     // batch size 1, bert.cpp:960-1020; per-sentence results do not depend on batching).  Inputs go through in groups:
-    // group g+1 is tokenized while group g is on the GPU, and the id buffers stay bounded for any n_inputs.
-    constexpr int32_t GROUP = 4096;
-    struct Group {
-        std::vector<bert_vocab_id> ids;
-        std::vector<int32_t> n_tokens;
-        std::vector<bert_vocab_id *> ptrs;
-    } groups[2];
-    auto tokenize_group = [&](Group &g, int32_t i0, int32_t n) {
-        g.ids.resize((size_t)N * n);
-        g.n_tokens.resize(n);
-        g.ptrs.resize(n);
-        for (int32_t i = 0; i < n; ++i) g.ptrs[i] = g.ids.data() + (size_t)i * N;
-        tokenize_many(ctx, n_threads, n, texts + i0, g.ids.data(), g.n_tokens.data());
+    // group g+1 is tokenized AND PACKED while group g is on the GPU (cu_seqlens and the ids back to back, what
+    // bert_eval_batch would do first thing with the GPU idle: 0.1 us per text, 1.7 ms for 16384 — round 5's trace of this
+    // function), and the id buffers stay bounded for any n_inputs.  The groups GROW — 2048, 4096, 8192, then 16384 texts: the
+    // first one is all a caller waits for with an idle GPU, later ones amortise the fixed costs of a blocking evaluation
+    // and fill the GPU better (1.17 M texts/s at 2048 texts of 25 tokens, 1.37 M at 16384); a remainder of less than a quarter
+    // of a group joins the last one.  Tokenizing a group of twice the size still fits under its predecessor's evaluation.
+    if (!ctx->engine()) { fprintf(stderr, "bert_encode_batch: this context has no device weights (tokenizer-only)\n"); return -1; }
+    if (ctx->inject_bad_alloc) throw std::bad_alloc();           // test knob: the path an exhausted host takes
+    auto group_size = [](int k, int32_t left) {
+        const int32_t g = (int32_t)(2048 << std::min(k, 3));
+        return left - g < g / 4 ? left : g;
     };
-    tokenize_group(groups[0], 0, std::min(GROUP, n_inputs));
+    bert_ctx::EncodeGroup *groups = ctx->enc_group;
+    auto tokenize_group = [&](bert_ctx::EncodeGroup &g, int32_t i0, int32_t n) {
+        const size_t need = (size_t)N * n;
+        if (g.ids_cap < need) { g.ids.reset(new bert_vocab_id[need]); g.ids_cap = need; }
+        g.n_tokens.resize(n);
+        tokenize_many(ctx, n_threads, n, texts + i0, g.ids.get(), g.n_tokens.data());
+        g.cu.resize((size_t)n + 1);
+        g.cu[0] = 0;
+        g.n_ok = n;
+        for (int32_t i = 0; i < n; ++i) {
+            // (the tokenizer's ids are in range by construction; its counts are 2 .. n_max_tokens)
+            if (g.n_tokens[i] <= 0 || g.n_tokens[i] > N) { g.n_ok = i; break; }
+            g.cu[i + 1] = g.cu[i] + g.n_tokens[i];
+        }
+        const size_t T = (size_t)g.cu[g.n_ok];
+        if (g.packed_cap < T) { g.packed.reset(new bert_vocab_id[T + T / 4]); g.packed_cap = T + T / 4; }
+        for (int32_t i = 0; i < g.n_ok; ++i) memcpy(g.packed.get() + g.cu[i], g.ids.get() + (size_t)i * N, sizeof(bert_vocab_id) * g.n_tokens[i]);
+    };
+#ifdef BERT_HIP_HOST_TRACE
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+#endif
+    tokenize_group(groups[0], 0, group_size(0, n_inputs));
+#ifdef BERT_HIP_HOST_TRACE
+    fprintf(stderr, "[encode] first group tokenized in %.3f ms\n", now() - t_begin);
+#endif
     int32_t total = 0;
-    for (int32_t i0 = 0, k = 0; i0 < n_inputs; i0 += GROUP, ++k) {
-        const int32_t n = std::min(GROUP, n_inputs - i0), n_next = std::min(GROUP, n_inputs - i0 - n);
+    for (int32_t i0 = 0, k = 0; i0 < n_inputs; ++k) {
+        const int32_t n = group_size(k, n_inputs - i0), n_next = n_inputs - i0 - n > 0 ? group_size(k + 1, n_inputs - i0 - n) : 0;
         std::thread ahead;
         std::exception_ptr ahead_error;
         if (n_next > 0) {
@@ -418,13 +455,26 @@ static int32_t encode_batch_impl(struct bert_ctx *ctx, int32_t n_threads, int32_
         }
         int32_t done = -1;
         std::exception_ptr eval_error;
-        try { done = eval_batch_impl(ctx, n, groups[k & 1].ptrs.data(), groups[k & 1].n_tokens.data(), embeddings + i0); }
-        catch (...) { eval_error = std::current_exception(); }
+#ifdef BERT_HIP_HOST_TRACE
+        const double t_e0 = now();
+#endif
+        try {
+            bert_ctx::EncodeGroup &g = groups[k & 1];
+            if (g.n_ok < n) fprintf(stderr, "bert_encode_batch: input %d cannot be evaluated (%d tokens)\n", i0 + g.n_ok, g.n_tokens[g.n_ok]);
+            done = g.n_ok > 0 ? eval_packed_rows(ctx, g.packed.get(), g.cu.data(), g.n_ok, embeddings + i0) : 0;
+        } catch (...) { eval_error = std::current_exception(); }
+#ifdef BERT_HIP_HOST_TRACE
+        const double t_e1 = now();
+#endif
         if (ahead.joinable()) ahead.join();                   // never leave the scope with a running thread
+#ifdef BERT_HIP_HOST_TRACE
+        fprintf(stderr, "[encode] group %d: %d texts, eval %.3f ms, then waited %.3f ms for the tokenizer\n", k, n, t_e1 - t_e0, now() - t_e1);
+#endif
         if (eval_error) std::rethrow_exception(eval_error);
         if (ahead_error) std::rethrow_exception(ahead_error);
         total += done > 0 ? done : 0;
         if (done != n) break;                                 // outputs after the failure stay untouched
+        i0 += n;
     }
     return total;
 }

@@ -722,16 +722,20 @@ def test_encode_equals_tokenize_plus_eval(make_model, tmp_path):
         assert ids[0] == 101 and ids[-1] == 102
         assert np.array_equal(e, m.eval(ids))
         assert np.array_equal(e, m.encode(t))
-    # more inputs than one group (4096) of bert_encode_batch: group g+1 is tokenized while group g is on the GPU
+    # more inputs than one group of bert_encode_batch (groups of 2048, 4096, 8192, then 16384 texts: group g+1 is tokenized while
+    # group g is on the GPU; the groups' id buffers belong to the context and are reused by later calls)
     rng = np.random.default_rng(8)
     pool = ["hello", "world", "testing", "tests", "a", "b", "c", ",", ".", "!", "HELLO", "xyzzy"]
-    many = [" ".join(rng.choice(pool, size=int(rng.integers(0, 12)))) for _ in range(9001)]
+    many = [" ".join(rng.choice(pool, size=int(rng.integers(0, 12)))) for _ in range(15001)]
     enc = m.encode_batch(many, n_threads=5)
     ids = m.tokenize_batch(many, n_threads=3)
     want = m.eval_batch(ids)
     assert np.array_equal(enc, want)
-    for i in (0, 4095, 4096, 8191, 8192, 9000):
+    for i in (0, 2047, 2048, 6143, 6144, 14335, 14336, 15000):
         assert np.array_equal(enc[i], m.encode(many[i])), i
+    # a later, smaller call on the same context: nothing of the earlier groups' ids shows through
+    few = many[7000:7000 + 2500][::-1]
+    assert np.array_equal(m.encode_batch(few, n_threads=2), want[7000:7000 + 2500][::-1])
 
 
 @pytest.mark.parametrize("dims,ftype", [("tiny-h128", "q4_0"), ("tiny-d64", "q4_1"), ("minilm-l6", "q4_0"), ("tiny", "q4_1")])
