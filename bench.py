@@ -170,7 +170,14 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
         model.reserve(T, B)
     stream = torch.cuda.current_stream(device)
     counts = [B] * world
-    d_all = torch.empty((world * B, H), dtype=torch.float32, device=device) if world > 1 else None
+    # N > 1: two result buffers and two gathered matrices — the exchange of step k (RCCL's own stream) runs under the forward
+    # pass of step k + 1, which writes the other pair; a buffer is reused only after the exchange that read it has finished
+    # ("per super-batch, overlapped with the next super-batch's compute").  Everything is finished inside
+    # the timed region: it ends with a device-wide synchronize.
+    d_outs = [d_out, torch.empty_like(d_out)] if world > 1 and d_out is not None else [d_out]
+    d_alls = [torch.empty((world * B, H), dtype=torch.float32, device=device) for _ in range(2)] if world > 1 else None
+    works = [None, None]
+    turn = [0]
 
     h_out = np.empty((B, H), dtype=np.float32) if cfg.get("host_step") else None
     if cfg.get("gather_step"):
@@ -184,10 +191,16 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
         if cfg.get("gather_step"):
             gathered["ptr"] = model.eval_packed_gather(flat, cu)[0]
             return
-        model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_out.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            # RCCL over xGMI: the path's one exchange step (bert.cpp_amd/dist.py), [world*B, H] on every rank
-            bdist.gather_embeddings(d_out, counts, out=d_all)
+        if world == 1:
+            model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_out.data_ptr(), stream.cuda_stream)
+            return
+        i = turn[0] & 1
+        turn[0] += 1
+        if works[i] is not None:
+            works[i].wait()                                   # (orders the launch stream behind the exchange that read d_outs[i])
+        model.eval_packed_device(d_tokens.data_ptr(), d_cu.data_ptr(), B, T, max_len, d_outs[i].data_ptr(), stream.cuda_stream)
+        # RCCL over xGMI: the path's one exchange step (bert.cpp_amd/dist.py), [world*B, H] on every rank
+        works[i] = bdist.gather_embeddings(d_outs[i], counts, out=d_alls[i], async_op=True)[1]
 
     def reduce_max(dt):
         if world == 1:
@@ -210,7 +223,10 @@ def run_config(cfg_id, args, rank, world, device, dist, torch, tmpdir, steps=Non
     regions = timed_regions(step, steps, warmup if warmup is not None else args.warmup, repeat or args.repeat,
                             lambda: torch.cuda.synchronize(device), dist.barrier if world > 1 else None, reduce_max, warm_step)
     dt = float(np.median(regions))
-    out = torch.from_numpy(h_out) if h_out is not None else d_out
+    for w in works:
+        if w is not None:
+            w.wait()
+    out = torch.from_numpy(h_out) if h_out is not None else d_outs[(turn[0] - 1) & 1 if world > 1 and turn[0] else 0]
     if cfg.get("gather_step"):
         # the gathered matrix lives in the context's device buffer: fetch a copy through torch (hipMemcpy D2H)
         import ctypes
@@ -298,7 +314,7 @@ def kernel_roofline(res, torch, device, steps=5, sync=None, groups=3):
         if res["cfg"].get("host_step"):
             timing += " — a host-paced step (staging, copies): the GPU idles in it, so this is an UPPER bound of the kernel's time (the device-resident entry of the same batch has the kernel's own)"
         if res.get("world", 1) > 1:
-            timing += " — the step ends with the RCCL all-gather of the embeddings, which this difference books on the kernel: an UPPER bound of its time"
+            timing += " — the RCCL all-gather of a step's embeddings runs under the next step's forward pass; what is not hidden of it this difference books on the kernel: an UPPER bound of its time"
     else:
         avg_s, K, n = replay_avg(name, pair_avg_s)
         timing = f"{K} back-to-back launches between one HIP event pair on the launch stream, median of {n} such groups"
@@ -765,6 +781,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # BERT_BENCH_SHARED_GPU=1 (a validation aid for a box with fewer GPUs than ranks, never a measurement): the ranks share the
+    # visible GPUs round robin and exchange over gloo — RCCL refuses two ranks on one device — so that the N > 1 code path of this
+    # file (barriers, max over ranks, the gather per step, the rank-0 line) can be run end to end on the 1-GPU box
+    shared = os.environ.get("BERT_BENCH_SHARED_GPU", "") not in ("", "0") and world > 1
+    if shared:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # one rank = one GPU: the rank's context lives on its own device only
@@ -773,7 +795,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -799,8 +824,10 @@ def main():
                 "config": {"workload": cfg["name"], "per_gpu_batch": cfg["batch"], "global_batch": cfg["batch"] * world,
                            "seq_len": cfg["seq_len"], "weights": cfg["ftype"],
                            "parallelism": f"dp{world} (replicated weights, sharded sentences"
-                                          + (", RCCL all-gather of embeddings per step)" if world > 1 else ")")},
+                                          + (", RCCL all-gather of embeddings per step, under the next step's forward pass)" if world > 1 else ")")},
             }
+            if shared:
+                contract["validation_only"] = "BERT_BENCH_SHARED_GPU: the ranks share the box's GPU(s) and exchange over gloo — not a scaling measurement"
             if "host_api" in e:
                 # SURVEY.md §8(d) quotes the metric host to host; the bench contract keeps `value` on HBM-resident inputs
                 # ("the PCIe-inclusive rate ... is never `value`"), so the host-to-host rate travels beside it, in `config` too

@@ -39,13 +39,15 @@ def shard_bounds(lengths: Sequence[int], world: int) -> List[Tuple[int, int]]:
     return bounds
 
 
-def gather_embeddings(local, counts: Sequence[int], group=None, out=None):
+def gather_embeddings(local, counts: Sequence[int], group=None, out=None, async_op=False):
     """All-gather variable-sized shards of embeddings.
 
     local: torch tensor [counts[rank], H] on the rank's device; returns [sum(counts), H] in global
     sentence order on every rank.  One collective: shards are padded to the largest count so a
     single all_gather_into_tensor moves everything.  `out` (optional, equal shards only) is a
-    preallocated [sum(counts), H] result buffer."""
+    preallocated [sum(counts), H] result buffer.
+    async_op (equal shards only): returns (out, work) without waiting — the exchange of one batch runs under the forward
+    pass of the next one; the caller waits on `work` before it reuses `local` or reads `out`."""
     import torch
     import torch.distributed as dist
 
@@ -56,8 +58,9 @@ def gather_embeddings(local, counts: Sequence[int], group=None, out=None):
         # equal shards (fixed-length batches, the benchmark case): no padding, no copies
         if out is None:
             out = torch.empty((world * counts[0], H), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-        return out
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=async_op)
+        return (out, work) if async_op else out
+    assert not async_op, "gather_embeddings(async_op=True) needs equal shards"
     mx = max(max(counts), 1)
     pad = torch.zeros((mx, H), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local

@@ -68,3 +68,49 @@ def test_sharded_encode_matches_single_process(tmp_path, world, n_sent):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == ref.shape
         assert np.array_equal(got, ref)            # same code per sentence wherever it runs: bit-exact
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    """bench.py's N > 1 step: two result buffers in turn, the exchange of step k left running under step k + 1
+    (gather_embeddings(async_op=True)); a buffer is rewritten only after the exchange that read it was waited for."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, H, steps = 5, 7, 6
+        locals_ = [torch.empty((B, H)), torch.empty((B, H))]
+        alls = [torch.empty((world * B, H)), torch.empty((world * B, H))]
+        works = [None, None]
+        seen = []
+        for k in range(steps):
+            i = k & 1
+            if works[i] is not None:
+                works[i].wait()
+                seen.append(alls[i].clone())
+            locals_[i].copy_(torch.full((B, H), float(100 * k + rank)) + torch.arange(B)[:, None])
+            out, works[i] = bdist.gather_embeddings(locals_[i], [B] * world, out=alls[i], async_op=True)
+            assert out is alls[i]
+        for k in (steps - 2, steps - 1):
+            works[k & 1].wait()
+            seen.append(alls[k & 1].clone())
+        torch.save(torch.stack(seen), os.path.join(out_dir, f"overlap{rank}.pt"))
+        # unequal shards cannot be exchanged without the wait
+        with pytest.raises(AssertionError):
+            bdist.gather_embeddings(torch.zeros((rank + 1, H)), [r + 1 for r in range(world)], async_op=True)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gather_left_running_under_the_next_step(tmp_path, world):
+    import torch
+    import torch.multiprocessing as mp
+
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    B, H, steps = 5, 7, 6
+    want = torch.stack([torch.cat([torch.full((B, H), float(100 * k + r)) + torch.arange(B)[:, None] for r in range(world)]) for k in range(steps)])
+    for r in range(world):
+        assert torch.equal(torch.load(tmp_path / f"overlap{r}.pt"), want), r
