@@ -26,6 +26,7 @@
 // + two), M_pad % 256 == 0, N <= 8192 (bias in LDS); everything else stays on gemm256 / gemm_mfma.
 #include "tile_stream.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace bert_hip {
@@ -36,9 +37,11 @@ namespace {
 #define G3_LDS(p) ((__attribute__((address_space(3))) void *)(p))
 
 constexpr int G3_BM = 256, G3_BN = 192, G3_BK = 64;
-constexpr int G3_W_OFF = 256 * 128;              // the weight tile behind the activation tile (256 rows x 128 bytes)
-constexpr int G3_STAGE = 65536;                  // stage stride (56 KiB used: address ^ 64 KiB switches stages)
-constexpr int G3_BIAS_OFF = 2 * G3_STAGE;        // bias[N] f32 behind the two stages
+// LDS: a ring of THREE activation tiles (256 rows x 128 bytes: requested two reduction tiles ahead — they come from HBM, and the
+// finished tiles' stores share the way), a ring of two weight tiles (192 rows: one ahead, L2), eight 2 KiB staging areas = 160 KiB
+constexpr int G3_A_SLOT = 256 * 128, G3_W_BASE = 3 * G3_A_SLOT, G3_W_SLOT = 192 * 128, G3_STG_BASE = G3_W_BASE + 2 * G3_W_SLOT;
+constexpr int G3_LDS_BYTES = G3_STG_BASE + 8 * 2048;
+static_assert(G3_LDS_BYTES == 160 * 1024, "the whole LDS of a CU");
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -76,13 +79,6 @@ struct G3Frag {
 // everything but the newest five reads (the next k-step's) has landed
 __device__ __forceinline__ void g3_wait5(G3Frag &f) {
     asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
-}
-struct G3Bias { f32x4 v[4]; };
-__device__ __forceinline__ void g3_wait5_bias(G3Frag &f, G3Bias &b) {
-    asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]) : : "memory");
-}
-__device__ __forceinline__ void g3_wait0_bias(G3Frag &f, G3Bias &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(b.v[0]), "+v"(b.v[1]), "+v"(b.v[2]), "+v"(b.v[3]) : : "memory");
 }
 // reduction-tile barrier: this wave's LDS-DMA pieces of the tile have landed — everything but the PEND newest vector-memory
 // operations, which are the stores / residual requests issued behind the pieces —, its fragment reads of the previous tile
@@ -136,55 +132,54 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
     int tile = t_begin + (int)(blockIdx.x >> 3);
     if (tile >= t_end) return;
 
-    // ---- the bias vector, once: the first k-step of every output tile reads its C operand from here
-    {
-        float *bl = (float *)(smem + G3_BIAS_OFF);
-        for (int i = tid; i < N; i += 512) bl[i] = p.bias[i];
-    }
-    __syncthreads();
-
     // ---- LDS-DMA: a reduction tile is 32 + 24 pieces of 1 KiB (8 rows each); a wave issues activation pieces 4 wave .. + 3 and
     // weight pieces 3 wave .. + 2.  Source offsets (elements): row (lane >> 3) of the piece, 16-byte chunk (lane & 7) ^ ((r >> 1) & 7)
     // with r = 8 piece + (lane >> 3): ((lane >> 4) + 4 (piece & 1)) & 7.
     // An odd piece's chunk differs in bit 2: offset ^ 32 (K is a multiple of 64).
     const unsigned off_e = (unsigned)((lane >> 3) * K) + ((((unsigned)lane & 7) ^ (((unsigned)lane >> 4) & 7)) << 3);
-    auto dma_piece = [&](const half_t *na, const half_t *nw, char *nstage, auto i_tag) __attribute__((always_inline)) {
-        constexpr int i = decltype(i_tag)::value;       // 0..3: activation pieces, 4..6: weight pieces
-        if constexpr (i < 4) {
-            const int pc = wave * 4 + i;
-            __builtin_amdgcn_global_load_lds(G3_GLOBAL(na + (size_t)pc * 8 * K + (off_e ^ ((i & 1) ? 32u : 0u))), G3_LDS(nstage + pc * 1024), 16, 0, 0);
-        } else {
-            const int pc = wave * 3 + (i - 4);
-            __builtin_amdgcn_global_load_lds(G3_GLOBAL(nw + (size_t)pc * 8 * K + (off_e ^ (unsigned)((pc & 1) << 5))), G3_LDS(nstage + G3_W_OFF + pc * 1024), 16, 0, 0);
-        }
+    // (slots as LDS byte offsets, scalars: a_off of the activation tile being multiplied, w_off of its weight tile)
+    auto dma_a = [&](const half_t *src, int slot_off, auto i_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value;       // 0..3
+        const int pc = wave * 4 + i;
+        __builtin_amdgcn_global_load_lds(G3_GLOBAL(src + (size_t)pc * 8 * K + (off_e ^ ((i & 1) ? 32u : 0u))), G3_LDS(smem + slot_off + pc * 1024), 16, 0, 0);
+    };
+    auto dma_w = [&](const half_t *src, int slot_off, auto i_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value;       // 0..2
+        const int pc = wave * 3 + i;
+        __builtin_amdgcn_global_load_lds(G3_GLOBAL(src + (size_t)pc * 8 * K + (off_e ^ (unsigned)((pc & 1) << 5))), G3_LDS(smem + slot_off + pc * 1024), 16, 0, 0);
     };
 
-    // ---- fragment addresses: k-step kk of stage s reads at (address of k-step 0, stage 0) ^ (kk << 5) ^ (s << 16) — the chunk
-    // swizzle is an XOR and a row's 128 bytes are aligned
+    // ---- fragment addresses: k-step kk reads at ((address of k-step 0 in slot 0) ^ (kk << 5)) + slot offset — the chunk swizzle is
+    // an XOR and a row's 128 bytes are aligned
     const unsigned aA0 = (unsigned)(size_t)smem + (unsigned)((wq * 64 + l31) * 128) + (unsigned)(((hi ^ ((l31 >> 1) & 7)) << 4));
-    const unsigned aW0 = (unsigned)(size_t)smem + (unsigned)(G3_W_OFF + (wf * 96 + l31) * 128) + (unsigned)(((hi ^ ((l31 >> 1) & 7)) << 4));
-    unsigned stage_x = 0;                              // (scalar) 0 / 64 KiB: the stage the fragment reads go to
+    const unsigned aW0 = (unsigned)(size_t)smem + (unsigned)((wf * 96 + l31) * 128) + (unsigned)(((hi ^ ((l31 >> 1) & 7)) << 4));
+    int a_off = 0, w_off = G3_W_BASE;                  // (scalars) the slots the fragment reads go to
     auto read_frag = [&](G3Frag &f, auto kk_tag) __attribute__((always_inline)) {
         constexpr int kk = decltype(kk_tag)::value;
-        const unsigned x = stage_x | (unsigned)(kk << 5);
-        const unsigned w = aW0 ^ x, a = aA0 ^ x;
+        const unsigned w = (aW0 ^ (unsigned)(kk << 5)) + (unsigned)w_off, a = (aA0 ^ (unsigned)(kk << 5)) + (unsigned)a_off;
         f.a[0] = g3_read_b128<0>(w); f.a[1] = g3_read_b128<4096>(w); f.a[2] = g3_read_b128<8192>(w);
         f.b[0] = g3_read_b128<0>(a); f.b[1] = g3_read_b128<4096>(a);
     };
-    auto toggle_stage = [&]() __attribute__((always_inline)) { stage_x ^= (unsigned)G3_STAGE; };
+    // the slots after the ones being multiplied: the weight tile one ahead goes to w_next(), the activation tile two ahead to a_prev()
+    // (the slot whose tile was multiplied in the reduction tile before this one)
+    auto w_next = [&]() __attribute__((always_inline)) { return w_off == G3_W_BASE ? G3_W_BASE + G3_W_SLOT : G3_W_BASE; };
+    auto a_prev = [&]() __attribute__((always_inline)) { return a_off == 0 ? 2 * G3_A_SLOT : a_off - G3_A_SLOT; };
+    auto advance_slots = [&]() __attribute__((always_inline)) {
+        a_off = a_off == 2 * G3_A_SLOT ? 0 : a_off + G3_A_SLOT;
+        w_off = w_next();
+    };
 
     f32x16 acc[3][2];                                 // [feature block][token block]
     // the finished tile, rounded, in the accumulator layout: ou[4 b + g] = features 32 i + 8 g + 4 hi .. + 3 (two f16 pairs) of token
     // 32 j + l31, block b = 2 i + j; the same registers receive the next tile's residual once the block has left
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 ou[24];
-    // ---- a finished block [32 features][32 tokens] leaves through the wave's 2 KiB STAGING area (the 8 KiB a stage leaves
-    // unused behind its tiles: waves 0-3 in stage 0's, 4-7 in stage 1's): four ds_write_b64 in the accumulator layout, two
+    // ---- a finished block [32 features][32 tokens] leaves through the wave's 2 KiB STAGING area (behind the tile rings): four ds_write_b64 in the accumulator layout, two
     // ds_read_b128 in the row layout, two global stores of 16 rows x 64 bytes.  (Stored straight from the accumulator layout —
     // v_permlane32_swap pairs make 16 bytes per lane — an instruction touches 32 rows x 2 x 16 bytes, no two lanes of a quad in one
     // line: 7.5 us per output tile and CU went into the stores' 64 requests each, 8 us into residual loads of that shape.)
     // LDS image [32 rows][64 bytes], the 16-byte chunk c of row r at position c ^ ((r >> 1) & 3).
-    char *const stg = smem + (wave & 4 ? G3_STAGE : 0) + 7 * 8192 + (wave & 3) * 2048;
+    char *const stg = smem + G3_STG_BASE + wave * 2048;
     // (the three lane-dependent addresses below are rebuilt from a fresh lane id at every use — v_mbcnt: two instructions, no
     // register held across the reduction tiles that have none to spare, and no scratch reload among the hand-counted requests)
     auto fresh_lane = []() __attribute__((always_inline)) { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); };
@@ -268,10 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         }
     };
     // a block's way out as the filler of a reduction tile's k-steps 1 and 2: GELU of its eight registers behind MFMAs 0..5 of
-    // k-step 1 and 0, 1 of k-step 2, the staging writes behind MFMA 2, the row reads behind 3; the two STORES go out right behind
-    // the next reduction-tile barrier, in front of that tile's first LDS-DMA request: a store queues behind every load its CU has
-    // in flight (issued behind the tile's pieces it cost 1.2-1.5 us per reduction tile — the pieces' own latency, measured: no
-    // barrier wait, no store target changes it), and at the barrier nothing is
+    // k-step 1 and 0, 1 of k-step 2, the staging writes behind MFMA 2, the row reads behind 3, the two stores behind 5
     auto store_fill_1 = [&](auto b_tag, auto m_tag) __attribute__((always_inline)) { gelu_reg(b_tag, m_tag); };
     auto store_fill_2 = [&](const char *ctile, auto b_tag, auto m_tag) __attribute__((always_inline)) {
         constexpr int m = decltype(m_tag)::value;
@@ -279,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         else if constexpr (m == 1) gelu_reg(b_tag, std::integral_constant<int, 7>{});
         else if constexpr (m == 2) stage_write(b_tag);
         else if constexpr (m == 3) stage_read();
-        else if constexpr (m == 5 && (G3_ABLATE & 64)) store_rows(ctile, b_tag);     // (ablation bit 6: the stores behind the pieces again)
+        else if constexpr (m == 5) store_rows(ctile, b_tag);
     };
 
 #define G3_OU_ALL "+v"(ou[0]), "+v"(ou[1]), "+v"(ou[2]), "+v"(ou[3]), "+v"(ou[4]), "+v"(ou[5]), "+v"(ou[6]), "+v"(ou[7]), "+v"(ou[8]), "+v"(ou[9]), \
@@ -300,20 +292,21 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         });
     };
     auto no_fill = [](auto) __attribute__((always_inline)) {};
-    // the deferred last k-step of a reduction tile with the first four pieces of the tile after the one just opened
-    auto dma_fill_a = [&](const half_t *na, const half_t *nw, char *nstage, auto m_tag) __attribute__((always_inline)) {
+    // the requests of a reduction tile: the weight tile ONE ahead (three pieces, first: the next barrier waits for them and leaves
+    // everything issued behind them in flight) between the MFMAs of the deferred last k-step, the activation tile TWO ahead (four
+    // pieces) between those of k-step 0
+    auto dma_fill_w = [&](const half_t *nw, auto m_tag) __attribute__((always_inline)) {
         constexpr int m = decltype(m_tag)::value;
-        if constexpr (m == 0) dma_piece(na, nw, nstage, I0{});
-        else if constexpr (m == 1) dma_piece(na, nw, nstage, I1{});
-        else if constexpr (m == 3) dma_piece(na, nw, nstage, I2{});
-        else if constexpr (m == 4) dma_piece(na, nw, nstage, I3{});
+        if constexpr (m == 0) dma_w(nw, w_next(), I0{});
+        else if constexpr (m == 2) dma_w(nw, w_next(), I1{});
+        else if constexpr (m == 4) dma_w(nw, w_next(), I2{});
     };
-    // k-step 0: the three weight pieces
-    auto dma_fill_b = [&](const half_t *na, const half_t *nw, char *nstage, auto m_tag) __attribute__((always_inline)) {
+    auto dma_fill_a = [&](const half_t *na, auto m_tag) __attribute__((always_inline)) {
         constexpr int m = decltype(m_tag)::value;
-        if constexpr (m == 0) dma_piece(na, nw, nstage, I4{});
-        else if constexpr (m == 2) dma_piece(na, nw, nstage, I5{});
-        else if constexpr (m == 4) dma_piece(na, nw, nstage, I6{});
+        if constexpr (m == 0) dma_a(na, a_prev(), I0{});
+        else if constexpr (m == 1) dma_a(na, a_prev(), I1{});
+        else if constexpr (m == 3) dma_a(na, a_prev(), I2{});
+        else if constexpr (m == 4) dma_a(na, a_prev(), I3{});
     };
 
     G3Frag f0, f1;
@@ -335,8 +328,8 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) {
             if constexpr (KIND == 1) store_fill_2(ctile, B{}, m);
         });
-        toggle_stage();
-        return KIND == 1 && (G3_ABLATE & 64) ? ((G3_ABLATE & 1) ? 0 : (G3_ABLATE & 32) ? 3 : 2) : 0;      // (a residual request must have landed at the next barrier)
+        advance_slots();
+        return KIND == 1 ? ((G3_ABLATE & 1) ? 0 : 2) : 0;      // (a residual request must have landed at the next barrier)
     };
 #ifdef BERT_HIP_TIMELINE
     // phase clock of the tuning build: per kind of reduction tile (0 plain, 1 a block leaves, 2 residual request, 3 the first tile of
@@ -347,9 +340,8 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
     auto clocked_barrier = [&](int pend, int next_kind) __attribute__((always_inline)) {
         unsigned long long t0, t1, t2;
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) : : "memory");
-        if (pend == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        if (pend == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)"
                      : "=s"(t1), "=s"(t2), "+v"(f1.a[0]), "+v"(f1.a[1]), "+v"(f1.a[2]), "+v"(f1.b[0]), "+v"(f1.b[1]) : : "memory");
         if (t_prev) { clk[clk_kind][0] += t0 - t_prev; clk[clk_kind][1] += t1 - t0; clk[clk_kind][2] += t2 - t1; clk[clk_kind][3] += 1; }
@@ -358,9 +350,9 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
     auto barrier_pend = [&](int pend) __attribute__((always_inline)) { clocked_barrier(pend, 0); };
 #else
     auto barrier_pend = [&](int pend) __attribute__((always_inline)) {
-        if (pend == 0) g3_barrier<0>(f1);
-        else if (pend == 2) g3_barrier<2>(f1);
-        else g3_barrier<(G3_ABLATE & 32) ? 63 : 3>(f1);     // (ablation bit 5: the barrier behind a leaving block waits for nothing of its own tile: wrong results, the stores' acknowledgements off the path)
+        // (the four activation pieces of the tile after next were issued last, or in front of a leaving block's two stores)
+        if (pend == 0) g3_barrier<4>(f1);
+        else g3_barrier<6>(f1);
     };
 #endif
 
@@ -375,19 +367,33 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
                 ou[4 * m + g][r] = __builtin_bit_cast(unsigned, h);
             }
     };
-    // the C operand of block (i, j)'s first MFMA: the bias runs of block row i, plus the residual that waits in the block's units
-    auto first_c = [&](const G3Bias &b, auto m_tag) __attribute__((always_inline)) -> f32x16 {
-        constexpr int m = decltype(m_tag)::value;
+    // the C operand of block (i, j)'s first MFMA: register e = bias[feature 32 i + 8 (e >> 2) + 4 hi + (e & 3)] (+ the residual that
+    // waits in the block's registers).  The bias comes through SCALAR loads (a wave-uniform address: 32 consecutive floats per
+    // block row, the lane halves pick theirs) — the LDS has no byte left for it beside the rings and the staging areas.
+    // (hand-issued s_load_dwordx16: the compiler takes a uniform address through the VECTOR memory path when stores may alias it,
+    // and waits for such a load with a vmcnt(0) that drains the LDS-DMA pieces in flight)
+    auto bias_row = [&](const float *brow, bool upper) __attribute__((always_inline)) -> f32x16 {
+        f32x16 s0, s1;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(s0), "=&s"(s1) : "s"(brow) : "memory");
         f32x16 c;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) c[e] = b.v[e >> 2][e & 3];
+        for (int e = 0; e < 16; ++e) {
+            const int k = 8 * (e >> 2) + (e & 3);
+            const float lo = k < 16 ? s0[k] : s1[k - 16], hi_ = k + 4 < 16 ? s0[k + 4] : s1[k + 4 - 16];
+            c[e] = upper ? hi_ : lo;
+        }
+        return c;
+    };
+    auto first_c = [&](const f32x16 &cb, auto m_tag) __attribute__((always_inline)) -> f32x16 {
+        constexpr int m = decltype(m_tag)::value;
+        f32x16 c = cb;
         if constexpr (RESID) {
             // c = bias + (float)residual in ONE instruction per value (v_fma_mix_f32: f16 x 1.0 + f32, the f32 add's bits): no
-            // converted copy of the block beside the bias runs, and nothing the compiler could hoist above the wait for them
+            // converted copy of the block beside the bias runs
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const unsigned w = ou[4 * m + (e >> 2)][(e & 3) >> 1];
-                const float bb = c[e];
+                const float bb = cb[e];
                 float r;
                 if (e & 1) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(bb));
                 else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(bb));
@@ -396,54 +402,39 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         }
         return c;
     };
-    unsigned bias_addr = 0;                            // this lane's first bias run of the current output tile
-    auto set_bias_addr = [&](int n0_) __attribute__((always_inline)) {
-        const int hi_ = fresh_lane() >> 5;
-        bias_addr = (unsigned)(size_t)smem + (unsigned)(G3_BIAS_OFF + (n0_ + wf * 96 + 4 * hi_) * 4);
-    };
-    auto read_bias = [&](G3Bias &b, auto i_tag) __attribute__((always_inline)) {
-        constexpr int i = decltype(i_tag)::value;
-        b.v[0] = g3_read_f32x4<i * 128>(bias_addr); b.v[1] = g3_read_f32x4<i * 128 + 32>(bias_addr);
-        b.v[2] = g3_read_f32x4<i * 128 + 64>(bias_addr); b.v[3] = g3_read_f32x4<i * 128 + 96>(bias_addr);
-    };
-    // k-step 0 of an output tile (fragments f0 requested, the bias runs of block row 0 requested behind them, f1 = k-step 1
-    // requested behind those): per block, the old accumulators into the result registers (PREV), then the first MFMA with
-    // C = bias (+ residual); the three weight pieces of the next reduction tile ride along
+    // k-step 0 of an output tile (fragments f0 requested; F1_EARLY: f1 = k-step 1 requested behind them): per block, the old
+    // accumulators into the result registers (PREV), then the first MFMA with C = bias (+ residual); the activation pieces of the
+    // tile after next ride along
+    // (the residual form has no registers for k-step 1's fragments beside the residual and the C operand: it requests them behind
+    // this step, F1_EARLY false)
     constexpr bool F1_EARLY = !RESID;
-    auto first_step = [&](auto prev_tag, G3Bias &b, const half_t *na, const half_t *nw, char *nstage) __attribute__((always_inline)) {
+    auto first_step = [&](auto prev_tag, const float *btile, const half_t *na) __attribute__((always_inline)) {
         constexpr bool PREV = decltype(prev_tag)::value;
-        // (the residual form has no registers for k-step 1's fragments beside the residual, the bias runs and the C operand:
-        // it requests them behind this step, F1_EARLY false)
-        if constexpr (F1_EARLY) g3_wait5_bias(f0, b);
-        else g3_wait0_bias(f0, b);
+        const bool upper = fresh_lane() >= 32;
+        if constexpr (F1_EARLY) g3_wait5(f0);
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0.a[0]), "+v"(f0.a[1]), "+v"(f0.a[2]), "+v"(f0.b[0]), "+v"(f0.b[1]) : : "memory");
         static_for<3>([&](auto i_tag) __attribute__((always_inline)) {
             constexpr int i = decltype(i_tag)::value;
+            const f32x16 cb = bias_row(btile + wf * 96 + i * 32, upper);
             static_for<2>([&](auto j_tag) __attribute__((always_inline)) {
                 constexpr int j = decltype(j_tag)::value;
                 using M = std::integral_constant<int, i * 2 + j>;
-                const f32x16 c = first_c(b, M{});
+                const f32x16 c = first_c(cb, M{});
                 if constexpr (PREV && !(G3_ABLATE & 4)) convert_block(M{});
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0.a[i], f0.b[j], c, 0, 0, 0);
-                dma_fill_b(na, nw, nstage, M{});
+                dma_fill_a(na, M{});
                 __builtin_amdgcn_sched_barrier(0);
-                // (the residual form reads the bias runs once per BLOCK: they are its C operand's registers, the sum built in place)
-                if constexpr (!F1_EARLY && i * 2 + j < 5) {
-                    read_bias(b, std::integral_constant<int, (i * 2 + j + 1) / 2>{});
-                    g3_wait0_bias(f0, b);
-                }
             });
-            if constexpr (F1_EARLY && i < 2) {
-                read_bias(b, std::integral_constant<int, i + 1>{});
-                g3_wait0_bias(f1, b);
-            }
         });
         if constexpr (!F1_EARLY) read_frag(f1, I1{});
     };
 
     int m0 = (tile / cnt_n) * G3_BM, n0 = (n_begin + tile % cnt_n) * G3_BN;
-    {   // the first reduction tile of the first output tile
+    {   // the first two activation tiles and the first weight tile of the first output tile
         const half_t *a = p.A + (size_t)m0 * K, *w = p.w16 + (size_t)n0 * K;
-        static_for<7>([&](auto i) __attribute__((always_inline)) { dma_piece(a, w, smem, i); });
+        static_for<4>([&](auto i) __attribute__((always_inline)) { dma_a(a, 0, i); });
+        static_for<4>([&](auto i) __attribute__((always_inline)) { dma_a(a + G3_BK, G3_A_SLOT, i); });
+        static_for<3>([&](auto i) __attribute__((always_inline)) { dma_w(w, G3_W_BASE, i); });
     }
     if constexpr (RESID) {   // the first tile's residual, block by block through the staging area: six exposed round trips per launch
         const char *rt = (const char *)p.resid + ((size_t)m0 * N + n0) * 2;
@@ -455,20 +446,14 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
         });
         asm volatile("" : G3_OU_ALL : : "memory");       // (named outside the generic lambda: it would not capture what only an asm operand uses)
     }
-    int stage = 0;
-    G3Bias bv;
     {   // ---- reduction tile 0 of the first output tile
         asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        const half_t *na = p.A + (size_t)m0 * K + G3_BK, *nw = p.w16 + (size_t)n0 * K + G3_BK;
-        char *nstage = smem + G3_STAGE;
-        dma_piece(na, nw, nstage, I0{}); dma_piece(na, nw, nstage, I1{}); dma_piece(na, nw, nstage, I2{}); dma_piece(na, nw, nstage, I3{});
-        set_bias_addr(n0);
+        const half_t *ta0 = p.A + (size_t)m0 * K, *tw0 = p.w16 + (size_t)n0 * K;
+        dma_w(tw0 + G3_BK, w_next(), I0{}); dma_w(tw0 + G3_BK, w_next(), I1{}); dma_w(tw0 + G3_BK, w_next(), I2{});
         read_frag(f0, I0{});
-        read_bias(bv, I0{});
         if constexpr (F1_EARLY) read_frag(f1, I1{});
-        first_step(std::false_type{}, bv, na, nw, nstage);
+        first_step(std::false_type{}, p.bias + n0, ta0 + 2 * G3_BK);
         (void)steps_1_2(I0{}, I0{}, nullptr, nullptr);
-        stage ^= 1;
     }
     int pend = 0;
     bool have_prev = false;
@@ -476,61 +461,52 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
     for (;;) {
         const int next = tile + S;
         const bool more = next < t_end;
-        // (after the last output tile the stream requests this tile's first reduction tile once more: a request that
-        // is never read costs less than a branch around every request)
+        // (after the last output tile the stream requests this tile's first reduction tiles once more: requests that are
+        // never read cost less than a branch around every request)
         const int nm0 = more ? (next / cnt_n) * G3_BM : m0, nn0 = more ? (n_begin + next % cnt_n) * G3_BN : n0;
         const half_t *ta = p.A + (size_t)m0 * K, *tw = p.w16 + (size_t)n0 * K;
+        const half_t *nta = p.A + (size_t)nm0 * K, *ntw = p.w16 + (size_t)nn0 * K;
         const char *rtile = (const char *)p.resid + ((size_t)nm0 * N + nn0) * 2;
         // reduction tile kt >= 1 of the current output tile
-        auto period = [&](int kt, auto kind_tag, auto idx_tag, auto store_tag) __attribute__((always_inline)) {
-            constexpr int KIND = decltype(kind_tag)::value, IDX = decltype(idx_tag)::value, STORE = decltype(store_tag)::value;
+        auto period = [&](int kt, auto kind_tag, auto idx_tag) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_tag)::value, IDX = decltype(idx_tag)::value;
 #ifdef BERT_HIP_TIMELINE
             clocked_barrier(pend, KIND);
 #else
             barrier_pend(pend);
 #endif
-            // the next reduction tile (of this output tile, or the first of the next one) into the stage just released
-            // (a reduction tile that carries a block's way out is never the last one, the one with the last residual request always is)
-            const bool last = KIND == 1 ? false : KIND == 2 ? IDX == 5 : kt + 1 == nk;
-            const half_t *na = last ? p.A + (size_t)nm0 * K : ta + (kt + 1) * G3_BK;
-            const half_t *nw = last ? p.w16 + (size_t)nn0 * K : tw + (kt + 1) * G3_BK;
+            // the weight tile one ahead and the activation tile two ahead (of this output tile, or the first ones of the next) into
+            // the slots the barrier has just released
+            // (a reduction tile that carries a block's way out is one of the first six: nk >= 12)
+            const half_t *nw = KIND != 1 && kt + 1 >= nk ? ntw : tw + (kt + 1) * G3_BK;
+            const half_t *na = KIND != 1 && kt + 2 >= nk ? nta + (kt + 2 - nk) * G3_BK : ta + (kt + 2) * G3_BK;
             if (G3_ABLATE & 8) { na = p.A + (size_t)(blockIdx.x & 7) * 256 * K; nw = p.w16; }      // (every request to tiles that stay in the L2)
-            char *nstage = smem + (stage ^ 1) * G3_STAGE;
-            // (the block staged in the previous reduction tile: its rows go out while no load of this CU is in flight)
-            if constexpr (STORE >= 0 && !(G3_ABLATE & 66)) store_rows(ctile, std::integral_constant<int, g3_block(STORE >= 0 ? STORE : 0)>{});
             read_frag(f0, I0{});
             // (the residual block requested one reduction tile ago has landed behind the barrier's vmcnt(0): into its registers)
             if constexpr (KIND == 2 && IDX > 0 && !(G3_ABLATE & 2)) resid_fetch(std::integral_constant<int, g3_block(IDX > 0 ? IDX - 1 : 0)>{});
-            // the previous reduction tile's last k-step, with the new tile's first requests between its MFMAs
-            mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill_a(na, nw, nstage, m); });
+            // the previous reduction tile's last k-step, with the weight requests between its MFMAs
+            mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill_w(nw, m); });
             read_frag(f1, I1{}); g3_wait5(f0);
-            mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill_b(na, nw, nstage, m); });
+            mfma_step_with(f0, [&](auto m) __attribute__((always_inline)) { dma_fill_a(na, m); });
             pend = steps_1_2(kind_tag, idx_tag, ctile, rtile);
-            stage ^= 1;
         };
-        using NS = std::integral_constant<int, -1>;
         const bool loads = RESID && more;              // the next tile's residual: requests in reduction tiles nk - 6 .. nk - 1
         int kt = 1;
-        bool first_request_done = false;
-        if (have_prev) {
-            // the previous tile's blocks 1 .. 5 are staged in reduction tiles 1 .. 5 (block 0 was in reduction tile 0), each block's
-            // rows are stored at the start of the reduction tile after its staging
-            period(1, I1{}, I1{}, I0{}); period(2, I1{}, I2{}, I1{}); period(3, I1{}, I3{}, I2{}); period(4, I1{}, I4{}, I3{}); period(5, I1{}, I5{}, I4{});
-            if (loads && nk == 12) { period(6, I2{}, I0{}, I5{}); first_request_done = true; }
-            else period(6, I0{}, I0{}, I5{});
-            kt = 7;
+        if (have_prev) {                               // the previous tile's blocks 1 .. 5 leave (block 0 left in reduction tile 0)
+            period(1, I1{}, I1{}); period(2, I1{}, I2{}); period(3, I1{}, I3{}); period(4, I1{}, I4{}); period(5, I1{}, I5{});
+            kt = 6;
         }
-        for (const int kt_end = loads ? nk - 6 : nk; kt < kt_end; ++kt) period(kt, I0{}, I0{}, NS{});
+        for (const int kt_end = loads ? nk - 6 : nk; kt < kt_end; ++kt) period(kt, I0{}, I0{});
         if (loads) {
-            if (!first_request_done) period(nk - 6, I2{}, I0{}, NS{});
-            period(nk - 5, I2{}, I1{}, NS{}); period(nk - 4, I2{}, I2{}, NS{});
-            period(nk - 3, I2{}, I3{}, NS{}); period(nk - 2, I2{}, I4{}, NS{}); period(nk - 1, I2{}, I5{}, NS{});
+            period(nk - 6, I2{}, I0{}); period(nk - 5, I2{}, I1{}); period(nk - 4, I2{}, I2{});
+            period(nk - 3, I2{}, I3{}); period(nk - 2, I2{}, I4{}); period(nk - 1, I2{}, I5{});
         }
         if (!more) break;
         // ---- reduction tile 0 of the next output tile: the finished tile's last k-step, then k-step 0 with the hand-over
         ctile = (const char *)p.C + ((size_t)m0 * N + n0) * 2;
-        if (G3_ABLATE & 16) ctile = (const char *)p.C;     // (ablation bit 4: every tile of a workgroup to one place)
+        if (G3_ABLATE & 16) ctile = (const char *)p.C;
         tile = next; m0 = nm0; n0 = nn0;
+        // (the residual form: the last residual request has landed: vmcnt(0))
         if constexpr (RESID)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" : "+v"(f1.a[0]), "+v"(f1.a[1]), "+v"(f1.a[2]), "+v"(f1.b[0]), "+v"(f1.b[1]), G3_OU_ALL : : "memory");
 #ifdef BERT_HIP_TIMELINE
@@ -538,23 +514,19 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
 #else
         else barrier_pend(pend);
 #endif
-        const half_t *na = p.A + (size_t)m0 * K + G3_BK, *nw = p.w16 + (size_t)n0 * K + G3_BK;
-        char *nstage = smem + (stage ^ 1) * G3_STAGE;
-        set_bias_addr(n0);
         read_frag(f0, I0{});
-        read_bias(bv, I0{});
         if constexpr (RESID && !(G3_ABLATE & 2)) resid_fetch(std::integral_constant<int, g3_block(5)>{});
-        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill_a(na, nw, nstage, m); });
+        mfma_step_with(f1, [&](auto m) __attribute__((always_inline)) { dma_fill_w(ntw + G3_BK, m); });
         if constexpr (F1_EARLY) read_frag(f1, I1{});
-        first_step(std::true_type{}, bv, na, nw, nstage);
+        first_step(std::true_type{}, p.bias + n0, nta + 2 * G3_BK);
         have_prev = true;
         pend = steps_1_2(I1{}, I0{}, ctile, nullptr);      // (block 0 leaves)
-        stage ^= 1;
     }
-    // ---- the last output tile: its last k-step, then its six blocks at once (the request issued behind the last tile must
+    // ---- the last output tile: its last k-step, then its six blocks at once (the requests issued behind the last tile must
     // not outlive the workgroup: vmcnt(0))
 #ifdef BERT_HIP_TIMELINE
     clocked_barrier(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63) == 0) {
         unsigned long long *o = g3_clock + ((size_t)(blockIdx.x & 255) * 8 + wave) * 16;
         for (int k = 0; k < 4; ++k)
@@ -576,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void gemm192_kernel(Gemm192Args p) {
 }
 
 bool gemm192_supported(const GemmWeight &W, int M_pad) {
-    return W.type == GW_F16 && W.w16 != nullptr && W.N % G3_BN == 0 && W.N <= 8192 && W.K % G3_BK == 0 && W.K >= 12 * G3_BK &&      // (six reduction tiles of blocks leaving + six of residual requests)
+    return W.type == GW_F16 && W.w16 != nullptr && W.N % G3_BN == 0 && W.K % G3_BK == 0 && W.K >= 12 * G3_BK &&      // (six reduction tiles of blocks leaving + six of residual requests)
           
            M_pad % G3_BM == 0 && M_pad > 0 && (size_t)M_pad * W.N * 2 < ((size_t)1 << 31);
 }
@@ -591,6 +563,10 @@ void launch_gemm192(const GemmWeight &W, const half_t *A, const float *bias, con
     // the cheaper side
     a.n_groups = 1;
     if ((size_t)W.N * W.K * 2 > (size_t)3 << 20 && W.N >= 4 * W.K && a.n_tiles_n % 2 == 0 && M_pad / G3_BM >= 64) a.n_groups = 2;
+    if (const char *g = getenv("BERT_HIP_G3_GROUPS")) {      // (tuning) feature groups for matrices beyond 3 MiB
+        const int v = atoi(g);
+        if ((v == 1 || v == 2 || v == 4) && a.n_tiles_n % v == 0 && (size_t)W.N * W.K * 2 > (size_t)3 << 20 && M_pad / G3_BM >= 64) a.n_groups = v;
+    }
     static int n_cu[MAX_HIP_DEVICES] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -600,10 +576,10 @@ void launch_gemm192(const GemmWeight &W, const half_t *A, const float *bias, con
     }
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
-    const size_t lds = 2 * G3_STAGE + (size_t)W.N * 4;
+    const size_t lds = G3_LDS_BYTES;
     static DeviceFlags configured[3];
     auto go = [&](auto kernel, int e) {
-        configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G3_STAGE + 8192 * 4); });
+        configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES); });
         BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
     };
     switch (epilogue) {
