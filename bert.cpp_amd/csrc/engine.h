@@ -122,7 +122,7 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, gemm192_ = false, tail_ = true, latency_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     bool f32_file_ = false;           // every matrix and table of the file is f32: the f32 route can take it
     bool f32_exact_ = true;           // ... and takes it unless BERT_HIP_F32=f16 / set_option("f32", "f16")
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch

@@ -234,7 +234,6 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         if (atoi(f) >= 32) e->latency_tokens_ = atoi(f);
     }
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
-    if (const char *f = getenv("BERT_HIP_GEMM192")) e->gemm192_ = strcmp(f, "0") != 0;      // (tuning: 0 = the 256 x 256 tile kernel everywhere)
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (const char *c = getenv("BERT_HIP_WINDOW_SLOTS")) set_window_slots(atoi(c));
     // f32 files: f32 arithmetic like the reference's (f32_route.hip) unless BERT_HIP_F32=f16 asks for f16 operands and the fused kernels
@@ -346,7 +345,6 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
-    else if (key == "gemm192") gemm192_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "stage_kernel") stage_kernel_ = value != "0";
@@ -474,16 +472,13 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
 
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
                     half_t *C, int epi) {
-        // (gemm192: the output tile's epilogue under the next tile's MFMAs — f16 images of the H = 768 shapes; gemm256's bits)
-        const bool wide = W.mfma_ok && gemm192_ && gemm256_ && !gemm_naive_ && gemm192_supported(W.w, t_pad);
-        const bool big = !wide && W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
-        const bool tiled = !wide && !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
+        const bool big = W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
+        const bool tiled = !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
         // (which kernel family served the mat-mul: reported as "family:<kernel>_<weights>" lines of the profile)
         if (profiling_ && replay_name_.empty())
-            families_[std::string("family:") + (wide ? "gemm192" : big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (wide || big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
+            families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (wide) launch_gemm192(W.w, A, bias, resid, C, t_pad, epi, s);
-            else if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
@@ -593,9 +588,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             });
         } else {
             // (q4 files: the 4-bit planes of the stacked matrix where its f16 image overflows an XCD's L2 and gemm256 takes the launch)
-            // (unless gemm192 takes the f16 image: its epilogue under the next tile's MFMAs is worth more than the planes' smaller refetch)
-            const bool wide = L.qkv.mfma_ok && gemm192_ && gemm256_ && !gemm_naive_ && gemm192_supported(L.qkv.w, t_pad);
-            const bool planes = !wide && L.qkv_q4.w.qs && L.qkv_q4.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(L.qkv_q4.w, t_pad);
+            const bool planes = L.qkv_q4.w.qs && L.qkv_q4.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(L.qkv_q4.w, t_pad);
             gemm("gemm_qkv", planes ? L.qkv_q4 : L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
             timed("attention", att_flops, s, [&] {
                 if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))

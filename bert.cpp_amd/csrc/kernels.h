@@ -185,11 +185,6 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
 bool gemm256_supported(const GemmWeight &W, int M_pad);
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
                     int epilogue, hipStream_t stream);
-// The same mat-mul with the output tile's epilogue under the next tile's MFMAs (gemm192.hip): 256 x 192 x 64 tiles, 8 waves; f16
-// images, N % 192 == 0, K >= 768, M_pad % 256 == 0.  gemm256's bits.
-bool gemm192_supported(const GemmWeight &W, int M_pad);
-void launch_gemm192(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);

@@ -32,7 +32,7 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     GemmWeightStore ws;
     if (!ws.build({&t}, impl == 1, err)) { fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str()); return -1; }
     if (impl != 1 && !ws.mfma_ok) { fprintf(stderr, "bert_hip_test_gemm: shape not supported by the MFMA path\n"); return -2; }
-    const int M_pad = impl >= 3 ? (M + 255) / 256 * 256 : (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int M_pad = impl == 3 ? (M + 255) / 256 * 256 : (M + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
     DevBuf dA, dB, dR, dC;
     if (!dA.alloc((size_t)M_pad * K * 2, err) || !dC.alloc((size_t)M_pad * N * 2, err) || !dB.upload(bias, (size_t)N * 4, err)) {
         fprintf(stderr, "bert_hip_test_gemm: %s\n", err.c_str());
@@ -46,9 +46,6 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     if (impl == 3) {
         if (!gemm256_supported(ws.w, M_pad)) return -2;
         launch_gemm256(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
-    } else if (impl == 4) {
-        if (!gemm192_supported(ws.w, M_pad)) return -2;
-        launch_gemm192(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     } else if (impl == 0) launch_gemm_mfma(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M_pad, epilogue, nullptr);
     else launch_gemm_naive(ws.w, dA.as<half_t>(), dB.as<float>(), dR.as<half_t>(), dC.as<half_t>(), M, epilogue, nullptr);
     CK(hipGetLastError());

@@ -15,8 +15,7 @@ extern "C" {
  * C[M][N] = epilogue(A[M][K] (f16 bits) x W[N][K]^T + bias); W given in file layout of `wtype`
  * (row-major f32 / f16 / block_q4_0 / block_q4_1 bytes).  epilogue: 0 bias, 1 bias+GELU(tanh),
  * 2 bias+residual.  impl: 0 tiled MFMA kernel (gemm.hip; q4 blocks dequantised in the tile load), 1 naive, 3 the 256 x 256 tile
- * kernel (gemm256.hip; -2 unless f16/f32 weights and N % 256 == 0), 4 the 256 x 192 tile kernel with the epilogue under the next
- * tile's MFMAs (gemm192.hip; -2 unless f16 weights, N % 192 == 0 and K >= 768).  Output f16 bits.  Returns 0 on success.                  */
+ * kernel (gemm256.hip; -2 unless f16/f32 weights and N % 256 == 0).  Output f16 bits.  Returns 0 on success.                  */
 BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, const void *W,
                                     int32_t wtype, const float *bias, const uint16_t *resid,
                                     int32_t epilogue, int32_t impl, uint16_t *C);
