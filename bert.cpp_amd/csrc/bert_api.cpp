@@ -540,7 +540,19 @@ int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *t
         const int n_dev = (int)ctx->engines.size(), H = ctx->hp.n_embd;
         const bool exchange = n_dev > 1 || ctx->rccl_single;      // (test_rccl_single: a single device runs the step on a 1-rank communicator)
         std::string err;
-        auto fail = [&](const std::string &what) { fprintf(stderr, "%s: %s\n", me, what.c_str()); return (int32_t)-3; };
+        // (a failure after the first exchange has been issued must not return while earlier exchanges still write the gathered
+        // matrices and read the shard buffers: drain every exchange and engine stream first)
+        bool issued = false;
+        auto fail = [&](const std::string &what) {
+            fprintf(stderr, "%s: %s\n", me, what.c_str());
+            if (issued)
+                for (int d = 0; d < (int)ctx->engines.size(); ++d) {
+                    if (hipSetDevice(ctx->engines[d]->device()) != hipSuccess) continue;
+                    (void)hipStreamSynchronize(ctx->engines[d]->stream());
+                    if (d < (int)ctx->xstream.size() && ctx->xstream[d]) (void)hipStreamSynchronize(ctx->xstream[d]);
+                }
+            return (int32_t)-3;
+        };
         // per device: two shard buffers and the gathered [n_sentences][H] matrix (grow-only, owned by the context)
         if (ctx->shard_out.empty())
             for (int d = 0; d < 2 * n_dev; ++d) { ctx->shard_out.emplace_back(new DevBuf); if (d < n_dev) ctx->gathered.emplace_back(new DevBuf); }
@@ -616,6 +628,7 @@ int32_t bert_hip_eval_packed_gather(struct bert_ctx *ctx, const bert_vocab_id *t
                 for (int d = 0; d < n_dev; ++d) at[d] = dst[d] + (size_t)b0 * H;
                 ok = ctx->rccl.all_gather(src.data(), at.data(), bounds, H, ctx->xstream.data(), err);
             }
+            issued = true;                                    // (even a failed attempt may have queued part of the step)
             if (!ok) return fail(err);
             for (int d = 0; d < n_dev; ++d)
                 if (hipSetDevice(devs[d]) != hipSuccess || hipEventRecord(ctx->xdone[2 * d + sl], ctx->xstream[d]) != hipSuccess) return fail("hipEventRecord failed");

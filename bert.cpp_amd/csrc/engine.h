@@ -69,11 +69,11 @@ public:
     // short enough on average for packing to pay, else sentences are placed by the uniform rule of qkv_attention2.hip
     int eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int n_sentences, int n_tokens, int max_len,
                            float *d_out, hipStream_t stream, float *d_hidden, std::string &err,
-                           const int2 *d_windows = nullptr, int n_windows = 0);
+                           const int2 *d_windows = nullptr, int n_windows = 0, int window_slots = 0);      // window_slots: the place granularity d_windows was built with (0: read it now)
     // next-fit packing of whole sentences (in order, each starting at a multiple of 16 slots) into windows of 128 token
     // slots: {first sentence, count} per window.  Sentences longer than a window get one of their own (the fused kernel is
     // not used for such batches).
-    static void build_windows(const int32_t *cu_seqlens, int n_sentences, std::vector<int2> &windows);
+    static void build_windows(const int32_t *cu_seqlens, int n_sentences, std::vector<int2> &windows, int slots);
     int eval_hidden(const int32_t *tokens, int n_tokens, float *hidden, float *embedding, std::string &err);
 
     // sizes the workspace for batches of up to n_tokens tokens / n_sentences sentences now, so that later calls of

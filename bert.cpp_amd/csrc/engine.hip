@@ -219,11 +219,19 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         err = std::string("unsupported GPU architecture '") + prop.gcnArchName + "' (kernels are built for gfx950 / MI355X only)";
         delete e; return nullptr;
     }
-    // BERT_HIP_KERNELS = fused (default) | tiled (GEMM + attention + LayerNorm kernels, Q|K|V and the intermediate through HBM)
-    // | naive (the generic kernels: any shape, row-major f16 images); finer switches: bert_hip_set_option
+    // BERT_HIP_KERNELS = fused (default) | tiled (GEMM + attention + LayerNorm kernels, Q|K|V and the intermediate through HBM);
+    // finer switches: bert_hip_set_option.  The GENERIC kernels (any shape, row-major f16 images) are what shapes outside the MFMA
+    // kernels' reach fall back to; running a whole model on them is a cross-check for the tests, not a route of the product:
+    // "naive" is understood by libbert_test.so only (this file compiled with -DBERT_HIP_TEST_ROUTES).
     if (const char *k = getenv("BERT_HIP_KERNELS")) {
+#ifdef BERT_HIP_TEST_ROUTES
         if (strcmp(k, "naive") == 0) e->gemm_naive_ = e->attn_naive_ = true;
-        else if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false, e->one_launch_ = 0;
+        else
+#else
+        if (strcmp(k, "naive") == 0) fprintf(stderr, "BERT_HIP_KERNELS=naive: a test cross-check (libbert_test.so), not a route of libbert.so; ignored\n");
+        else
+#endif
+        if (strcmp(k, "tiled") == 0) e->qkv2_ = e->tail_ = e->latency_ = false, e->one_launch_ = 0;
     }
     // (the cap of the latency route: measured on H = 384; a window of an H = 128 model costs the fused kernels less than five
     // launches cost the route, so such models keep the one-window cap)
@@ -333,6 +341,12 @@ int Engine::check(std::string &err) {
 }
 
 void Engine::set_option(const std::string &key, const std::string &value) {
+#ifndef BERT_HIP_TEST_ROUTES
+    if ((key == "gemm" || key == "attn") && value == "naive") {
+        fprintf(stderr, "bert_hip_set_option: %s=naive is a test cross-check (libbert_test.so), not a route of libbert.so; ignored\n", key.c_str());
+        return;
+    }
+#endif
     if (key == "gemm") {
         // the generic kernel reads GemmWeight::naive16, an image that is only built at load time (BERT_HIP_KERNELS=naive) or
         // for shapes the MFMA kernels cannot take: refuse the switch when a matrix lacks it
@@ -440,9 +454,8 @@ std::string Engine::profile_report() {
     return out;
 }
 
-void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows) {
-    windows.clear();
-    const int slot = window_slots();                          // 16 (or 8: kernels.h)
+void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows, int slot) {
+    windows.clear();                                          // slot: 16 (or 8: kernels.h), the value the pass read once
     int first = 0, fill = 0;                                  // open window: sentences first .. b-1 occupy `fill` slots
     for (int b = 0; b < B; ++b) {
         const int n = cu[b + 1] - cu[b];
@@ -456,8 +469,11 @@ void Engine::build_windows(const int32_t *cu, int B, std::vector<int2> &windows)
 }
 
 int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int B, int T, int max_len, float *d_out,
-                               hipStream_t s, float *d_hidden, std::string &err, const int2 *d_windows, int n_windows) {
+                               hipStream_t s, float *d_hidden, std::string &err, const int2 *d_windows, int n_windows, int slots_in) {
     if (B <= 0 || T <= 0) return 0;
+    // the windows' place granularity, read ONCE per pass (the host path read it when it built its list): the window list, the
+    // grid bound and the kernels' place rule must agree whatever another thread or context sets meanwhile
+    const int slots = slots_in ? slots_in : window_slots();
     HIP_OK(hipSetDevice(device_), err, -1);
     const int H = hp_.n_embd, I = hp_.n_intermediate, nh = hp_.n_head, dh = H / nh;
     const int t_pad = (T + 255) / 256 * 256;                 // whole tiles of every kernel family (128- and 256-token tiles)
@@ -509,18 +525,18 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     }
     const bool full_windows = (long long)B * 128 == T;
     if (!d_windows && fused_windows) {
-        const int spw = qkv_attention2_sentences_per_window(max_len), uniform = (B + spw - 1) / spw;
+        const int spw = qkv_attention2_sentences_per_window(max_len, slots), uniform = (B + spw - 1) / spw;
         // (forced one-launch: the kernel takes a window list or one sentence per window — its layer-tail phase needs a window's
         // tokens to be at most 128 whatever the sentences' lengths turn out to be)
-        if (4ll * uniform * 128 > 5 * ((long long)T + (long long)(window_slots() / 2) * B) || (one_launch_ok && one_launch_ == 2 && spw > 1 && !full_windows)) {
+        if (4ll * uniform * 128 > 5 * ((long long)T + (long long)(slots / 2) * B) || (one_launch_ok && one_launch_ == 2 && spw > 1 && !full_windows)) {
             int *count = status_.as<int>() + 1;
-            timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, s); });
+            timed("build_windows", 0.0, s, [&] { launch_build_windows(d_cu, B, windows_.as<int2>(), count, slots, s); });
             d_windows = windows_.as<int2>();
             d_n_windows = count;
             // upper bound from T and B alone (the extra workgroups return at once): "never more than the uniform rule" only
             // holds for batches that keep their max_len promise, and a broken promise must cost the offender its row, not
             // a neighbour its window
-            n_windows = qkv_attention2_max_windows(B, T);
+            n_windows = qkv_attention2_max_windows(B, T, slots);
         }
     }
     // When it pays: the layer-tail phase costs a window 128 rows' time however few tokens it holds, the layer-tail KERNEL runs
@@ -529,7 +545,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     bool one_launch_pays = full_windows || one_launch_ == 2;
     if (!one_launch_pays && !d_n_windows) {
         const long long n_win = d_windows ? n_windows : B;
-        one_launch_pays = (d_windows || qkv_attention2_sentences_per_window(max_len) == 1) && 100ll * T >= 95ll * 128 * n_win;
+        one_launch_pays = (d_windows || qkv_attention2_sentences_per_window(max_len, slots) == 1) && 100ll * T >= 95ll * 128 * n_win;
     }
     // The latency route (skinny.hip): at most 128 tokens = one window of the fused kernels, which would keep one CU of 256 busy
     // per launch.  Same bits per sentence (the route must not show in the results), seven short launches per layer.
@@ -576,7 +592,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
                       L.ffi_b.as<float>(), L.ffo_b.as<float>(), L.ln_out_w.as<float>(), L.ln_out_b.as<float>()};
         }
         timed("model_kernel", hp_.n_layer * (2.0 * Td * 3 * H * H + att_flops + 2.0 * Td * H * H + 4.0 * Td * H * I), s, [&] {
-            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, d_out, max_len, status_.as<int>(), s);
+            launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, d_out, max_len, status_.as<int>(), slots, s);
         });
     }
     for (int il = 0; !skinny && !one_launch && il < hp_.n_layer; ++il) {
@@ -584,7 +600,7 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
         if (qkv2_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths
             timed("qkv_attention2", 2.0 * Td * L.qkv.w.N * L.qkv.w.K + att_flops, s, [&] {
-                launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, d_n_windows, max_len, nh, ctx, s);
+                launch_qkv_attention2(L.qkv.w, x, L.qkv_b.as<float>(), d_cu, B, d_windows, n_windows, d_n_windows, max_len, nh, slots, ctx, s);
             });
         } else {
             // (q4 files: the 4-bit planes of the stacked matrix where its f16 image overflows an XCD's L2 and gemm256 takes the launch)
@@ -758,6 +774,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
     };
     auto fail = [&]() { (void)hipStreamSynchronize(stream_); return -1; };        // nothing may stay queued on the slots
     std::vector<int2> windows;
+    const int slots = window_slots();                         // (once per call: the lists below and the kernels that place by them)
     for (size_t i = 0; i < chunks.size(); ++i) {
         HostSlot &sl = slot_[i & 1];
         const int b0 = chunks[i].b0, nb = chunks[i].b1 - b0, T = cu[chunks[i].b1] - cu[b0];
@@ -767,14 +784,15 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         for (int j = 0; j <= nb; ++j) h_cu[j] = cu[b0 + j] - cu[b0];
         int n_windows = 0;
         if (chunks[i].max_len <= 128) {
-            build_windows(h_cu, nb, windows);
+            build_windows(h_cu, nb, windows, slots);
             n_windows = (int)windows.size();
             memcpy(sl.h_in + off_w, windows.data(), windows.size() * sizeof(int2));
         }
         const size_t staged = off_w + (size_t)n_windows * sizeof(int2);
         HOST_LAP("staged", i);
-        if (stage_kernel_ && staged <= ((size_t)2 << 20)) {
-            // (a small block: a few workgroups read it across the host link — the copy engine's start-up is ~20 us of a 0.8 ms call)
+        if (stage_kernel_ && staged <= ((size_t)256 << 10)) {
+            // (a small block — measured up to the 130 KB of a 256 x 128 batch: a few workgroups read it across the host link, the copy
+            // engine's start-up is ~20 us of a 0.8 ms call; full 1 MiB chunks stay with the copy engine, off the compute stream)
             launch_stage_copy(sl.d_in_host, sl.d_in.p, staged, stream_);
         } else if (hipMemcpyAsync(sl.d_in.p, sl.h_in, staged, hipMemcpyHostToDevice, stream_) != hipSuccess) {
             err = "hipMemcpyAsync (ids) failed";
@@ -784,7 +802,7 @@ int Engine::eval_packed_host(const int32_t *tokens, const int32_t *cu, int B, fl
         // host destination: the pooling kernel's rows go straight into the pinned block (no D2H copy behind the pass)
         float *out = d_embeddings ? sl.d_out.as<float>() : sl.d_out_host;
         if (eval_packed_device((const int32_t *)d_in, (const int32_t *)(d_in + off_cu), nb, T, chunks[i].max_len, out, stream_, nullptr, err,
-                               n_windows ? (const int2 *)(d_in + off_w) : nullptr, n_windows) != 0)
+                               n_windows ? (const int2 *)(d_in + off_w) : nullptr, n_windows, slots) != 0)
             return fail();
         if ((d_embeddings && hipMemcpyAsync(d_embeddings + (size_t)b0 * H, sl.d_out.p, (size_t)nb * H * 4, hipMemcpyDeviceToDevice, stream_) != hipSuccess) ||
             hipEventRecord(sl.done, stream_) != hipSuccess) {

@@ -205,7 +205,7 @@ bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const 
 // arguments and bits: [n_sentences][H] f32, max_len, status word).
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
                          int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, float *pooled, int max_len,
-                         int *status, hipStream_t stream);
+                         int *status, int slots, hipStream_t stream);
 // The latency route (skinny.hip): the weight mat-muls of a layer split by output features AND token blocks over up to 192
 // one-wave workgroups, for batches of at most 128 tokens; same bits per sentence as qkv_attention2 + layer_tail.
 // mode: 0 QKV projection (-> f16), 1 out-projection (+ x + bo -> f32), 2 up-projection + GELU (-> f16, fragment order),
@@ -242,16 +242,17 @@ void launch_attention_naive(const half_t *qkv, const int32_t *cu_seqlens, int n_
 // `groups` [n_groups] = {first sentence, count} per window (device memory), or nullptr: the uniform rule
 // 128 / round_up(max_len, 16) sentences per window.
 bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, int max_len);
-int qkv_attention2_sentences_per_window(int max_len);
+int qkv_attention2_sentences_per_window(int max_len, int slots);
 // n_groups_dev (optional): device word with the real number of windows when `groups` was built on the device and n_groups is
 // only an upper bound (launch_build_windows / qkv_attention2_max_windows).
 void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
                            int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
-                           half_t *out, hipStream_t stream);
+                           int slots, half_t *out, hipStream_t stream);
 // next-fit windows (the rule of Engine::build_windows) computed on the device from cu_seqlens; *n_windows receives their number
-void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream);
-int qkv_attention2_max_windows(int n_sentences, int n_tokens);
-// place granularity of the windows (16, or 8: qkv_attention2.hip), process-wide
+void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, int slots, hipStream_t stream);
+int qkv_attention2_max_windows(int n_sentences, int n_tokens, int slots);
+// place granularity of the windows (16, or 8: qkv_attention2.hip): the process-wide default; every function above takes the
+// value its caller read once per forward pass (`slots`)
 int window_slots();
 void set_window_slots(int slots);
 

@@ -148,11 +148,11 @@ bool model_kernel_supported(const GemmWeight &Wqkv, const GemmWeight &Wo, const 
 
 void launch_model_kernel(const ModelLayerWeights *layers, int n_layer, half_t *x, half_t *ctx, const int32_t *cu_seqlens, int n_sentences,
                          int n_tokens, const int2 *groups, int n_groups, const int *n_groups_dev, int n_head, float *pooled, int max_len,
-                         int *status, hipStream_t stream) {
+                         int *status, int slots, hipStream_t stream) {
     ModelArgs m;
     m.pooled = pooled; m.status = status; m.max_len = max_len;
     m.x = x; m.ctx = ctx; m.cu = cu_seqlens; m.groups = groups; m.n_groups = n_groups_dev;
-    m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N; m.slot_mask = window_slots() - 1;
+    m.n_layer = n_layer; m.n_head = n_head; m.n_sent = n_sentences; m.I = layers[0].W1->N; m.slot_mask = slots - 1;
     for (int l = 0; l < n_layer; ++l) {
         const ModelLayerWeights &s = layers[l];
         ModelLayerArgs &d = m.layer[l];

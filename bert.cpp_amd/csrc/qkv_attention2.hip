@@ -608,21 +608,23 @@ __global__ __launch_bounds__(BW_THREADS) void build_windows_kernel(const int32_t
     }
 }
 
-// The place granularity of the windows, process-wide (BERT_HIP_WINDOW_SLOTS / bert_hip_set_option "window_slots"): 16 — one k-step
+// The place granularity of the windows — the process-wide DEFAULT (BERT_HIP_WINDOW_SLOTS / bert_hip_set_option "window_slots"); a
+// forward pass reads it ONCE (Engine::eval_packed_*) and hands that value to the window builders, the grid bound and the
+// launchers, so a change from another thread or context cannot land between a window list and the kernel that places by it: 16 — one k-step
 // of the P·V MFMAs, so that a sentence's bits do not depend on where it sits in a window — or 8: a quarter fewer windows for
 // mean-25-token batches, and bits that depend on a sentence's place (tools/ubench/mfma_shift.hip).
 static std::atomic<int> g_window_slots{16};
 int window_slots() { return g_window_slots.load(std::memory_order_relaxed); }
 void set_window_slots(int slots) { g_window_slots.store(slots == 8 ? 8 : 16, std::memory_order_relaxed); }
 
-void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, hipStream_t stream) {
-    if (window_slots() == 8) BERT_LAUNCH(build_windows_kernel<8>, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
+void launch_build_windows(const int32_t *cu_seqlens, int n_sentences, int2 *windows, int *n_windows, int slots, hipStream_t stream) {
+    if (slots == 8) BERT_LAUNCH(build_windows_kernel<8>, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
     else BERT_LAUNCH(build_windows_kernel<16>, dim3(1), dim3(BW_THREADS), 0, stream, cu_seqlens, n_sentences, windows, n_windows);
 }
 
-int qkv_attention2_max_windows(int n_sentences, int n_tokens) {
+int qkv_attention2_max_windows(int n_sentences, int n_tokens, int slot) {
     // two consecutive next-fit windows hold more than 128 slots together
-    const long long slots = (long long)n_tokens + (long long)(window_slots() - 1) * n_sentences;
+    const long long slots = (long long)n_tokens + (long long)(slot - 1) * n_sentences;
     const long long bound = 2 * (slots / 128) + 2;
     return (int)(bound < n_sentences ? bound : n_sentences);
 }
@@ -633,15 +635,15 @@ bool qkv_attention2_supported(const GemmWeight &Wqkv, int n_head, int d_head, in
            max_len <= Q2_WIN && max_len > 0;
 }
 
-int qkv_attention2_sentences_per_window(int max_len) { const int m = window_slots() - 1; return Q2_WIN / ((max_len + m) & ~m); }
+int qkv_attention2_sentences_per_window(int max_len, int slots) { const int m = slots - 1; return Q2_WIN / ((max_len + m) & ~m); }
 
 void launch_qkv_attention2(const GemmWeight &Wqkv, const half_t *x, const float *bias, const int32_t *cu_seqlens,
                            int n_sentences, const int2 *groups, int n_groups, const int *n_groups_dev, int max_len, int n_head,
-                           half_t *out, hipStream_t stream) {
+                           int slots, half_t *out, hipStream_t stream) {
     Qkv2Args a;
     a.x = x; a.w = Wqkv.w16; a.qs = Wqkv.qs; a.sc = Wqkv.sc; a.bias = bias; a.cu = cu_seqlens; a.groups = groups; a.n_groups = n_groups_dev; a.out = out;
-    a.n_head = n_head; a.n_sent = n_sentences; a.slot_mask = window_slots() - 1;
-    a.spw = qkv_attention2_sentences_per_window(max_len);
+    a.n_head = n_head; a.n_sent = n_sentences; a.slot_mask = slots - 1;
+    a.spw = qkv_attention2_sentences_per_window(max_len, slots);
     const int grid = groups ? n_groups : (n_sentences + a.spw - 1) / a.spw;
     const int KT = Wqkv.K / 64, GB = KT / 2;
     const size_t lds = (size_t)3 * GB * Q2_TILE + 2 * (2 * Q2_WIN * 64 + 32 * Q2_VT_LD * 2) + (size_t)2 * Wqkv.K * sizeof(float);

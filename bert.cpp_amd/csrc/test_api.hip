@@ -110,18 +110,18 @@ int32_t bert_hip_test_qkv_attention(int32_t n_sentences, const int32_t *cu_seqle
         DevBuf dcount;
         int n_win = 0;
         if (fused == 2) {
-            Engine::build_windows(cu_seqlens, n_sentences, win);
+            Engine::build_windows(cu_seqlens, n_sentences, win, window_slots());
             if (!dwin.upload(win.data(), win.size() * sizeof(int2), err)) return -1;
             n_win = (int)win.size();
         } else if (fused == 4) {
             // the same windows built on the device; the grid is the launcher's upper bound
             if (!dwin.alloc((size_t)n_sentences * sizeof(int2), err) || !dcount.alloc(sizeof(int), err)) return -1;
-            launch_build_windows(dcu.as<int32_t>(), n_sentences, dwin.as<int2>(), dcount.as<int>(), nullptr);
-            n_win = qkv_attention2_max_windows(n_sentences, T);
+            launch_build_windows(dcu.as<int32_t>(), n_sentences, dwin.as<int2>(), dcount.as<int>(), window_slots(), nullptr);
+            n_win = qkv_attention2_max_windows(n_sentences, T, window_slots());
         }
         launch_qkv_attention2(ws.w, dx.as<half_t>(), db.as<float>(), dcu.as<int32_t>(), n_sentences,
                               fused == 3 ? nullptr : dwin.as<int2>(), n_win, fused == 4 ? dcount.as<int>() : nullptr, max_len, n_head,
-                              dout.as<half_t>(), nullptr);
+                              window_slots(), dout.as<half_t>(), nullptr);
         CK(hipGetLastError());
         CK(hipDeviceSynchronize());
     } else {
@@ -248,12 +248,12 @@ void bert_hip_test_shard_bounds(const int32_t *cu_seqlens, int32_t n_sentences, 
 
 int32_t bert_hip_test_build_windows(const int32_t *cu_seqlens, int32_t n_sentences, int32_t *windows) {
     std::vector<int2> w;
-    Engine::build_windows(cu_seqlens, n_sentences, w);
+    Engine::build_windows(cu_seqlens, n_sentences, w, window_slots());
     for (size_t i = 0; i < w.size(); ++i) { windows[2 * i] = w[i].x; windows[2 * i + 1] = w[i].y; }
     return (int32_t)w.size();
 }
 
-int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens) { return qkv_attention2_max_windows(n_sentences, n_tokens); }
+int32_t bert_hip_test_max_windows(int32_t n_sentences, int32_t n_tokens) { return qkv_attention2_max_windows(n_sentences, n_tokens, window_slots()); }
 
 int32_t bert_hip_test_set_window_slots(int32_t slots) { set_window_slots(slots); return window_slots(); }
 
@@ -262,7 +262,7 @@ int32_t bert_hip_test_build_windows_device(const int32_t *cu_seqlens, int32_t n_
     DevBuf dcu, dwin, dcount;
     if (!dcu.upload(cu_seqlens, (size_t)(n_sentences + 1) * sizeof(int32_t), err) ||
         !dwin.alloc((size_t)std::max(n_sentences, 1) * sizeof(int2), err) || !dcount.alloc(sizeof(int), err)) return -1;
-    launch_build_windows(dcu.as<int32_t>(), n_sentences, dwin.as<int2>(), dcount.as<int>(), nullptr);
+    launch_build_windows(dcu.as<int32_t>(), n_sentences, dwin.as<int2>(), dcount.as<int>(), window_slots(), nullptr);
     int n = -1;
     if (hipMemcpy(&n, dcount.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || n < 0 || n > n_sentences) return -1;
     if (n && hipMemcpy(windows, dwin.p, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost) != hipSuccess) return -1;

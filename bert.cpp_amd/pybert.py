@@ -49,14 +49,8 @@ def build(force: bool = False, jobs: int = 8) -> str:
 _lib = None
 
 
-def lib() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first "
-                           f"(python -c 'import __graft_entry__ as g; g.build()' or make -C bert.cpp_amd)")
-    L = C.CDLL(LIB_PATH)
+def _declare_product_abi(L):
+    """argument / result types of include/bert.h + include/bert_hip.h (libbert.so; libbert_test.so holds the same entry points)"""
     vp, i32, f32p, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.bert_load_from_file.restype = vp; L.bert_load_from_file.argtypes = [C.c_char_p]
     L.bert_hip_load_tokenizer.restype = vp; L.bert_hip_load_tokenizer.argtypes = [C.c_char_p]
@@ -89,6 +83,17 @@ def lib() -> C.CDLL:
     L.bert_hip_tokenize_batch.restype = i32
     L.bert_hip_tokenize_batch.argtypes = [vp, i32, i32, C.POINTER(C.c_char_p), i32p, i32p]
     L.bert_hip_version.restype = C.c_char_p
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build the HIP extension first "
+                           f"(python -c 'import __graft_entry__ as g; g.build()' or make -C bert.cpp_amd)")
+    L = C.CDLL(LIB_PATH)
+    _declare_product_abi(L)
     _lib = L
     return L
 
@@ -104,6 +109,7 @@ def test_lib() -> C.CDLL:
     if not os.path.exists(TEST_LIB_PATH):
         raise RuntimeError(f"{TEST_LIB_PATH} not found: build it first (make -C bert.cpp_amd)")
     L = C.CDLL(TEST_LIB_PATH)
+    _declare_product_abi(L)
     vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
@@ -222,8 +228,9 @@ def _i32p(a: np.ndarray):
 class BertModel:
     """Mirror of the reference's Python `BertModel` wrapper (examples/sample_dylib.py:12-59)."""
 
-    def __init__(self, fname: str, tokenizer_only: bool = False):
-        self.lib = lib()
+    def __init__(self, fname: str, tokenizer_only: bool = False, test_routes: bool = False):
+        # test_routes: the context lives in libbert_test.so, whose engine also understands the whole-model "naive" cross-check route
+        self.lib = test_lib() if test_routes else lib()
         load = self.lib.bert_hip_load_tokenizer if tokenizer_only else self.lib.bert_load_from_file
         self.ctx = load(fname.encode("utf-8"))
         if not self.ctx:

@@ -126,7 +126,10 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
- * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "window_slots" = "16" | "8" (process-wide), "chunk_tokens" = n, "profile_replay" (above).                                       */
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "window_slots" = "16" | "8" (process-wide default, read once
+ * per forward pass), "chunk_tokens" = n, "gather_super_tokens" = n (bert_hip_eval_packed_gather: tokens per device and super-batch, 0 =
+ * four device chunks), "stage_kernel" = "0" | "1" (host API: staged blocks of at most 256 KiB travel by a kernel that reads the mapped
+ * pinned memory instead of the copy engine), "profile_replay" (above).                                                                 */
 BERT_API void bert_hip_set_option(struct bert_ctx *ctx, const char *key, const char *value);
 
 BERT_API const char *bert_hip_version(void);

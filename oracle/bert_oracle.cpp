@@ -5,7 +5,7 @@
 //
 // PARITY STATUS
 //   * token ids: PINNED against the reference's own known-answer vectors
-//     (reference examples/test_tokenizer.cpp:70-73) — tests/test_tokenizer_golden.py.
+//     (reference examples/test_tokenizer.cpp:70-73) — tests/test_oracle.py (oracle) and tests/test_host.py (product tokenizer), re-run on the GPU box by tests/test_gpu_exactness.py.
 //   * embeddings: "PARITY UNPINNED" at the ggml boundary.  All arithmetic of the reference lives
 //     in ggerganov/ggml, an un-vendored, un-pinned git submodule (reference .gitmodules:1-3,
 //     /root/reference/ggml is empty) — the reference cannot be built here, and it ships no

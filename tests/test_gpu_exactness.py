@@ -12,7 +12,7 @@ import pytest
 import test_host
 import test_oracle
 import test_tools
-from test_host import fuzz_vocab_model  # noqa: F401  (fixture)
+from test_host import corpus_golden, fuzz_vocab_model  # noqa: F401  (fixtures)
 from test_tools import tools  # noqa: F401  (fixture)
 
 from bert_cpp_amd import pybert
@@ -28,6 +28,11 @@ def test_tokenizer_reference_known_answers_on_the_gpu_box(sparse_vocab_model, to
 def test_tokenizer_fuzz_matches_oracle_on_the_gpu_box(fuzz_vocab_model):  # noqa: F811
     test_host.test_tokenizer_fuzz_matches_oracle(fuzz_vocab_model)
     test_host.test_tokenize_batch_on_threads_equals_one_by_one(fuzz_vocab_model)
+
+
+def test_tokenizer_on_committed_reference_texts_on_the_gpu_box(corpus_golden):  # noqa: F811
+    """(the reference's sample texts: tests/test_host.py skips the mounted-tree form of this test on the GPU box)"""
+    test_host.test_tokenizer_on_committed_reference_texts(corpus_golden)
 
 
 @pytest.mark.parametrize("src", ["f32", "f16"])

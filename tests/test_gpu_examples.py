@@ -127,3 +127,19 @@ def test_server_protocol_and_concurrent_clients(text_model):
             srv.wait(20)
         except subprocess.TimeoutExpired:
             srv.kill()
+
+
+def test_scale_smoke_script_on_shared_gpu():
+    """tools/scale_smoke.sh — the first command for an N-GPU node — at N = 2 on THIS box (BERT_BENCH_SHARED_GPU=1: the torchrun ranks
+    share the GPU and exchange over gloo; the in-process arm runs at N = 1 with its exchange step on a 1-rank RCCL communicator): the
+    two-rank arms print the digests of N = 1 and the script exits 0; with one rank's row corrupted it exits non-zero."""
+    import subprocess
+    env = dict(os.environ, BERT_BENCH_SHARED_GPU="1", STEPS="3", BERT_HIP_QUIET="1")
+    env.pop("BERT_HIP_LATENCY", None)
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_smoke.sh"), "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "n=2" in r.stdout and "ranks_in_group=2" in r.stdout and "MISMATCH" not in r.stdout, r.stdout[-2000:]
+    assert '"validation_only"' in r.stdout, r.stdout[-1500:]          # (bench.py's two-rank line says what it is)
+    bad = subprocess.run(["bash", os.path.join(ROOT, "tools", "scale_smoke.sh"), "2"], cwd=ROOT, env=dict(env, SCALE_SMOKE_CORRUPT="1", STEPS="1"),
+                         capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and "MISMATCH" in bad.stdout, (bad.returncode, bad.stdout[-1500:])

@@ -817,6 +817,55 @@ def test_latency_route_gives_the_batch_route_s_bits(make_model, dims, ftype):
     assert np.array_equal(m.eval_batch(six), np.stack([batch[0]] * 6))
 
 
+@pytest.mark.parametrize("dims,ftype,q4", [("minilm-l6", "f16", None), ("minilm-l6", "q4_0", None), ("minilm-l6", "q4_1", "fused"),
+                                            ("h256-l3", "f16", None), ("h256-l3", "q4_0", "fused"), ("tiny-d64", "f16", None)])
+def test_shipped_latency_cap_through_every_entry_point(make_model, dims, ftype, q4, tmp_path, monkeypatch):
+    """The suite runs with BERT_HIP_LATENCY=128 (tests/conftest.py: the parity tests are meant for the batch kernels); the SHIPPED
+    default sends calls of up to 768 tokens down the latency route.  Here the default is what is loaded: calls of 129 .. 768
+    tokens through bert_eval_batch (row pointers in place and scattered), bert_hip_eval_packed and bert_encode_batch — f16, q4 expanded at load, q4 planes in HBM, d_head 32 (H = 384 / 256) and a d_head 64 model
+    the route declines — give the bits of the batch route (the same files loaded with the one-window cap), and match the oracle."""
+    gf.MODEL_DIMS.setdefault("h256-l3", gf.BertHParams(1000, 128, 256, 1024, 8, 3))
+    path, hp = make_model(dims, ftype, 3)
+    if q4:
+        monkeypatch.setenv("BERT_HIP_Q4", q4)
+    m_batch = pybert.BertModel(path)                         # conftest's cap: one window
+    monkeypatch.delenv("BERT_HIP_LATENCY")
+    m = pybert.BertModel(path)                               # the shipped default
+    rng = np.random.default_rng(21)
+    cap = min(hp.n_max_tokens, 128)
+    for lens in ([cap, 25, 1, 77 % cap + 1, 33, cap - 2, 64, 5][: 8], [cap] * 5, [7] * 40, [cap, cap, 3]):
+        sents = [rng.integers(0, hp.n_vocab, size=n).astype(np.int32) for n in lens]
+        total = sum(lens)
+        assert 128 < total <= 768, total
+        want = m_batch.eval_batch(sents)
+        m.profile(True)
+        got = m.eval_batch(sents)
+        names = set(m.profile_report())
+        m.profile(False)
+        # (the route under test is the one that ran; 4-bit planes in HBM and H < 256 are shapes the route declines: the batch kernels)
+        assert any(k.startswith("skinny") for k in names) == (dims != "tiny-d64" and q4 != "fused"), (dims, q4, names)
+        assert np.array_equal(got, want), (dims, ftype, lens, float(np.abs(got - want).max()))
+        assert np.array_equal(m.eval_batch(sents, scattered=True), want)
+        ids = np.concatenate(sents)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        assert np.array_equal(m.eval_packed(ids, cu), want)
+    o = orc.Oracle(path)
+    assert cosine(got[0], o.eval(sents[0])) >= TIGHT_COS_GGML[ftype]
+    # strings in: a vocabulary for the same weights
+    if dims == "minilm-l6" and ftype == "f16":
+        words = ["[PAD]"] * 100 + ["[UNK]", "[CLS]", "[SEP]"] + ["hello", "world", "##ing", "##s", "test", ",", ".", "!", "a", "b", "c"]
+        vocab = [w.encode() for w in words] + [f"[unused{i}]".encode() for i in range(len(words), hp.n_vocab)]
+        vpath = str(tmp_path / "vocab_model.bin")
+        gf.write_model(vpath, hp, gf.synthetic_weights(hp, 3), gf.FTYPE_F16, vocab=vocab)
+        mv = pybert.BertModel(vpath)
+        texts = ["hello world! " * 9, "testing tests, a b c.", "a", "hello " * 30] * 3         # ~500 tokens: the route
+        enc = mv.encode_batch(texts)
+        idl = [mv.tokenize(t) for t in texts]
+        assert 128 < sum(len(i) for i in idl) <= 768
+        monkeypatch.setenv("BERT_HIP_LATENCY", "128")
+        assert np.array_equal(enc, pybert.BertModel(vpath).eval_batch(idl))
+
+
 @pytest.mark.parametrize("ftype", ["f16", "q4_0"])
 @pytest.mark.parametrize("knob", ["tail=0", "qkv2=0", "kernels=tiled", "kernels=naive"])
 def test_kernel_families_agree_end_to_end(make_model, knob, ftype, monkeypatch):
@@ -833,7 +882,7 @@ def test_kernel_families_agree_end_to_end(make_model, knob, ftype, monkeypatch):
     key, value = knob.split("=")
     if key == "kernels":
         monkeypatch.setenv("BERT_HIP_KERNELS", value)
-        m_alt = pybert.BertModel(path)
+        m_alt = pybert.BertModel(path, test_routes=value == "naive")     # (the generic kernels as a whole-model route: libbert_test.so only)
         monkeypatch.delenv("BERT_HIP_KERNELS")
     else:
         m_alt = pybert.BertModel(path)

@@ -164,6 +164,35 @@ def test_tokenizer_on_reference_corpus_if_present(sparse_vocab_model):
                 assert m.tokenize(line) == o.tokenize(line)
 
 
+@pytest.fixture(scope="module")
+def corpus_golden(tmp_path_factory):
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "sample_texts_golden.json")) as f:
+        g = json.load(f)
+    path = str(tmp_path_factory.mktemp("corpus") / "corpus_vocab.bin")
+    write_vocab_only_model(path, g["vocab"], n_max_tokens=g["n_max_tokens"])
+    return g, path
+
+
+def test_tokenizer_on_committed_reference_texts(corpus_golden):
+    """The first 200 of the reference's own sample texts (tests/golden/sample_texts_golden.json, written by make_corpus_golden.py where the
+    reference tree is mounted): the product's bert_tokenize gives the ids the oracle's restatement of bert.cpp:199-325 gave — whole words,
+    multi-piece splits, punctuation, unmatched bytes, truncation at n_max_tokens — and the oracle still gives them too.  Runs on the GPU
+    box as well (tests/test_gpu_exactness.py), where /root/reference does not exist."""
+    g, path = corpus_golden
+    m = libbert.BertModel(path, tokenizer_only=True)
+    o = orc.Oracle(path, vocab_only=True)
+    texts = [t.encode("latin-1") for t in g["texts"]]
+    with silenced_stderr():
+        for t, want in zip(texts, g["ids"]):
+            assert m.tokenize(t) == want, t[:40]
+            assert o.tokenize(t) == want, t[:40]
+        for t, want in zip(texts, g["ids_n_max_12"]):
+            assert m.tokenize(t, 12) == want, t[:40]
+        assert m.tokenize_batch(texts, 4) == g["ids"]
+    assert sum(len(i) > 12 for i in g["ids"]) > 100 and max(len(i) for i in g["ids"]) == g["n_max_tokens"]
+
+
 def test_model_file_validation(tmp_path, capfd):
     hp = gf.MODEL_DIMS["tiny"]
     good = str(tmp_path / "good.bin")

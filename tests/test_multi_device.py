@@ -359,13 +359,19 @@ def test_gemm_option_toggled_after_load(make_model, capfd, monkeypatch):
     is refused now unless the images were built at load time; with them both families agree."""
     path, hp = make_model("tiny-h128", "f16", 1)
     s = [np.random.default_rng(0).integers(0, hp.n_vocab, size=n).astype(np.int32) for n in (9, 40, 64)]
-    m = pybert.BertModel(path)
+    m = pybert.BertModel(path, test_routes=True)
     base = m.eval_batch(s)
     m.set_option("gemm", "naive")
     assert "ignored" in capfd.readouterr().err
     assert np.array_equal(m.eval_batch(s), base)
+    # the product library does not know the route at all (a test cross-check: libbert_test.so's engine only)
     monkeypatch.setenv("BERT_HIP_KERNELS", "naive")
-    m2 = pybert.BertModel(path)
+    mp = pybert.BertModel(path)
+    assert "not a route of libbert.so" in capfd.readouterr().err
+    mp.set_option("attn", "naive")
+    assert "not a route of libbert.so" in capfd.readouterr().err
+    assert np.array_equal(mp.eval_batch(s), base)
+    m2 = pybert.BertModel(path, test_routes=True)
     monkeypatch.delenv("BERT_HIP_KERNELS")
     naive = m2.eval_batch(s)
     m2.set_option("gemm", "mfma")

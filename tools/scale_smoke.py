@@ -65,26 +65,39 @@ def main():
                     assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(p), ctypes.c_size_t(got.nbytes), 2) == 0
                     assert np.array_equal(got, host), f"device {dev}: gathered matrix differs from the host rows"
                 out.append(digest(host))
-            print(f"scale_smoke inproc n={n} digests {' '.join(out)}")
+            print(f"scale_smoke inproc n={n} devices_in_context={m.n_devices()} (one RCCL rank per device, communicator made at load) digests {' '.join(out)}")
         else:
             import torch
             import torch.distributed as dist
             from bert_cpp_amd import dist as bdist
             from bert_cpp_amd import pybert
             rank, local = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+            # BERT_BENCH_SHARED_GPU=1 (validation on a box with fewer GPUs than ranks, as in bench.py): the ranks share the GPUs round
+            # robin and exchange over gloo on host tensors — RCCL refuses two ranks on one device
+            shared = os.environ.get("BERT_BENCH_SHARED_GPU", "") not in ("", "0")
+            if shared:
+                local %= torch.cuda.device_count()
             torch.cuda.set_device(local)
             os.environ["BERT_HIP_DEVICES"] = str(local)
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            if shared:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             path = os.path.join(d, f"m{rank}.bin")
             gf.make_synthetic_model(path, "minilm-l6", "f16", seed=0)
             m = pybert.BertModel(path)
             out = []
             for sents in batches(hp):
-                emb = bdist.encode_sharded(lambda ss: m.eval_packed(*pack(ss)), sents, device=torch.device("cuda", local))
+                def ev(ss):
+                    rows = m.eval_packed(*pack(ss))
+                    if os.environ.get("SCALE_SMOKE_CORRUPT") and rank == dist.get_world_size() - 1 and len(rows):
+                        rows = rows.copy(); rows[0, 0] += 1.0       # (the harness's own check: a wrong row must fail the script)
+                    return rows
+                emb = bdist.encode_sharded(ev, sents, device="cpu" if shared else torch.device("cuda", local))
                 out.append(digest(emb.cpu().numpy()))
             if rank == 0:
-                print(f"scale_smoke torchrun n={dist.get_world_size()} digests {' '.join(out)}")
+                print(f"scale_smoke torchrun n={dist.get_world_size()} ranks_in_group={dist.get_world_size()} backend={dist.get_backend()} digests {' '.join(out)}")
             dist.destroy_process_group()
 
 
