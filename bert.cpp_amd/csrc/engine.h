@@ -39,6 +39,10 @@ struct GemmWeightStore {
     // want_f32: f32 tensors also keep their own f32 rows (GemmWeight::w32, the f32 route)
     bool build(const std::vector<const HostTensor *> &rows, bool want_naive, std::string &err, bool want_kperm = false,
                bool expand_q4 = false, bool want_f32 = false);
+    // LayerNorm folded into a mat-mul that consumes LayerNorm(u; gamma, beta) (kernels.h GemmLnFold): the f16 image of
+    // W diag(gamma) (this store) and the weight side of the statistics k-step, [N][16] f16: s_hi s_lo s_hi c_hi c_lo c_hi 0..
+    // with s[n] = sum_k W'[n][k], c[n] = sum_k beta[k] W[n][k] + bias[n]
+    bool build_ln_fold(const std::vector<const HostTensor *> &rows, const float *gamma, const float *beta, const float *bias, DevBuf &waug, std::string &err);
 };
 
 struct LayerWeights {
@@ -49,6 +53,12 @@ struct LayerWeights {
     // give the same bits and are 1-3 % faster on that launch: DESIGN.md §3).  Used by the QKV mat-mul of the gemm256 route only.
     GemmWeightStore qkv_q4;
     DevBuf qkv_b, o_b, ffi_b, ffo_b, ln_att_w, ln_att_b, ln_out_w, ln_out_b;
+    // LayerNorm folded into the H = 768 mat-muls (kernels.h GemmLnFold): the up-projection with this layer's attention LayerNorm
+    // folded in, the Q|K|V projection with the PREVIOUS layer's output LayerNorm (layers >= 1), their statistics columns, and
+    // the packed (gamma, beta + bias) pairs of the two residual mat-muls (attention output: the previous layer's output LayerNorm)
+    GemmWeightStore ffi_fold, qkv_fold;
+    DevBuf ffi_waug, qkv_waug, o_gb, ffo_gb;
+    bool fold_ok = false;
 };
 
 struct KernelStat { int launches = 0; double ms = 0.0; double flops = 0.0; };
@@ -105,6 +115,7 @@ private:
 
     // workspace (grow-only)
     DevBuf x_, qkv_, ctx_, y_, ff_, v32_, d_tokens_, d_cu_, d_out_, d_hidden_, status_, windows_;
+    DevBuf ln_stats1_, ln_stats2_, ln_rows1_, ln_rows2_;      // LayerNorm folding: per-row partial statistics / finalized rows of the two LayerNorms of a layer
     hipStream_t stream_ = nullptr;
     // the workspace serves ONE forward pass at a time: every pass waits for the previous one's event on its own stream
     hipEvent_t busy_ = nullptr;
@@ -122,7 +133,7 @@ private:
     } slot_[2];
 
     // options
-    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
+    bool gemm_naive_ = false, attn_naive_ = false, qkv2_ = true, gemm256_ = true, ln_fold_ = true, tail_ = true, latency_ = true, q4_expand_ = true;
     bool f32_file_ = false;           // every matrix and table of the file is f32: the f32 route can take it
     bool f32_exact_ = true;           // ... and takes it unless BERT_HIP_F32=f16 / set_option("f32", "f16")
     int one_launch_ = 1;              // all layers in one launch: 0 never, 1 when it pays (well-filled windows), 2 whenever the kernel takes the batch

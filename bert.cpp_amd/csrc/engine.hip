@@ -164,6 +164,49 @@ bool GemmWeightStore::build(const std::vector<const HostTensor *> &rows, bool wa
     return true;
 }
 
+bool GemmWeightStore::build_ln_fold(const std::vector<const HostTensor *> &rows, const float *gamma, const float *beta, const float *bias,
+                                    DevBuf &waug, std::string &err) {
+    const int64_t K = rows[0]->ne0;
+    int64_t N = 0;
+    for (auto *t : rows) { if (t->ne0 != K) { err = "stacked weights disagree in shape"; return false; } N += t->ne1; }
+    w.N = (int)N; w.K = (int)K; w.N_pad = (int)((N + GEMM_BN - 1) / GEMM_BN * GEMM_BN);
+    mfma_ok = (K % GEMM_BK == 0) && (N % 8 == 0);
+    if (!mfma_ok) return true;                                // (shapes the MFMA kernels do not take are never folded)
+    w.type = GW_F16;
+    std::vector<_Float16> img((size_t)w.N_pad * K, (_Float16)0), row((size_t)K), aug((size_t)N * 16, (_Float16)0);
+    int64_t n = 0;
+    for (auto *t : rows)
+        for (int64_t r = 0; r < t->ne1; ++r, ++n) {
+            row_to_f16(*t, r, row.data());                    // (the values the un-folded f16 image holds)
+            double s = 0.0, c = bias ? (double)bias[n] : 0.0;
+            for (int64_t k = 0; k < K; ++k) {
+                const _Float16 wf = (_Float16)((float)row[k] * gamma[k]);
+                img[(size_t)n * K + k] = wf;
+                s += (double)(float)wf;
+                c += (double)beta[k] * (double)(float)row[k];
+            }
+            const _Float16 s_h = (_Float16)(float)s, s_l = (_Float16)(float)(s - (double)(float)s_h);
+            const _Float16 c_h = (_Float16)(float)c, c_l = (_Float16)(float)(c - (double)(float)c_h);
+            _Float16 *a = aug.data() + (size_t)n * 16;
+            a[0] = s_h; a[1] = s_l; a[2] = s_h; a[3] = c_h; a[4] = c_l; a[5] = c_h;
+        }
+    if (!w16.upload(img.data(), img.size() * 2, err) || !waug.upload(aug.data(), aug.size() * 2, err)) return false;
+    w.w16 = w16.as<half_t>();
+    return true;
+}
+
+// packed (f16 gamma | f16 (beta + bias) << 16) per feature: what a residual mat-mul needs to rebuild LayerNorm(resid) per element
+static bool upload_gamma_beta_bias(DevBuf &b, const float *gamma, const float *beta, const float *bias, int64_t n, std::string &err) {
+    std::vector<uint32_t> v((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const _Float16 g = (_Float16)gamma[i], bb = (_Float16)(beta[i] + bias[i]);
+        uint16_t gu, bu;
+        memcpy(&gu, &g, 2); memcpy(&bu, &bb, 2);
+        v[(size_t)i] = (uint32_t)gu | ((uint32_t)bu << 16);
+    }
+    return b.upload(v.data(), v.size() * 4, err);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Engine
 // ------------------------------------------------------------------------------------------------
@@ -242,6 +285,7 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         if (atoi(f) >= 32) e->latency_tokens_ = atoi(f);
     }
     if (const char *f = getenv("BERT_HIP_Q4")) e->q4_expand_ = strcmp(f, "fused") != 0;
+    if (const char *f = getenv("BERT_HIP_LN_FOLD")) e->ln_fold_ = strcmp(f, "0") != 0;        // (tuning: 0 = LayerNorm kernels of their own at H = 768)
     if (const char *c = getenv("BERT_HIP_CHUNK_TOKENS")) { const int v = atoi(c); if (v > 0) e->chunk_tokens_ = v; }
     if (const char *c = getenv("BERT_HIP_WINDOW_SLOTS")) set_window_slots(atoi(c));
     // f32 files: f32 arithmetic like the reference's (f32_route.hip) unless BERT_HIP_F32=f16 asks for f16 operands and the fused kernels
@@ -303,6 +347,34 @@ Engine *Engine::create(const ModelFile &mf, int device, std::string &err) {
         ok = ok && upload_f32(L->ln_out_w, T(p + "output.LayerNorm.weight"), err);
         ok = ok && upload_f32(L->ln_out_b, T(p + "output.LayerNorm.bias"), err);
     }
+    // LayerNorm folding (kernels.h GemmLnFold; the route of models the fused H <= 384 kernels do not take): images for every layer
+    // whose four matrices run on gemm256's f16 form
+    for (int i = 0; ok && i < mf.hp.n_layer; ++i) {
+        LayerWeights &L = *e->layers_[i];
+        const std::string p = "encoder.layer." + std::to_string(i) + ".";
+        const int H = mf.hp.n_embd;
+        auto f16_256 = [](const GemmWeightStore &s) { return s.mfma_ok && s.w.type == GW_F16 && s.w.N % 256 == 0 && s.w.K % 64 == 0 && s.w.K >= 128; };
+        if (!(H > 384 && H % 256 == 0 && f16_256(L.qkv) && f16_256(L.o) && f16_256(L.ffi) && f16_256(L.ffo)) || e->f32_file_) continue;
+        auto F = [&](const std::string &n) { const HostTensor *t = T(n); return t ? (const float *)t->data : nullptr; };
+        const float *g1 = F(p + "attention.output.LayerNorm.weight"), *b1 = F(p + "attention.output.LayerNorm.bias");
+        const float *bi = F(p + "intermediate.dense.bias"), *bo2 = F(p + "output.dense.bias"), *bo = F(p + "attention.output.dense.bias");
+        if (!g1 || !b1 || !bi || !bo2 || !bo) continue;
+        ok = L.ffi_fold.build_ln_fold({T(p + "intermediate.dense.weight")}, g1, b1, bi, L.ffi_waug, err) &&
+             upload_gamma_beta_bias(L.ffo_gb, g1, b1, bo2, H, err);
+        if (ok && i >= 1) {
+            const std::string q = "encoder.layer." + std::to_string(i - 1) + ".";
+            const float *g2 = F(q + "output.LayerNorm.weight"), *b2 = F(q + "output.LayerNorm.bias");
+            std::vector<float> qb((size_t)3 * H);
+            const char *names[3] = {"attention.self.query.bias", "attention.self.key.bias", "attention.self.value.bias"};
+            bool have = g2 && b2;
+            for (int k = 0; have && k < 3; ++k) { const float *b = F(p + names[k]); have = b != nullptr; if (have) memcpy(qb.data() + (size_t)k * H, b, (size_t)H * 4); }
+            if (!have) continue;
+            ok = L.qkv_fold.build_ln_fold({T(p + "attention.self.query.weight"), T(p + "attention.self.key.weight"), T(p + "attention.self.value.weight")},
+                                          g2, b2, qb.data(), L.qkv_waug, err) &&
+                 upload_gamma_beta_bias(L.o_gb, g2, b2, bo, H, err);
+        }
+        L.fold_ok = ok && L.ffi_fold.mfma_ok && (i == 0 || L.qkv_fold.mfma_ok);
+    }
     ok = ok && e->status_.alloc(16, err);
     if (ok && hipStreamCreateWithFlags(&e->stream_, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; ok = false; }
     if (ok && hipEventCreateWithFlags(&e->busy_, hipEventDisableTiming) != hipSuccess) { err = "hipEventCreate failed"; ok = false; }
@@ -359,6 +431,7 @@ void Engine::set_option(const std::string &key, const std::string &value) {
     } else if (key == "attn") attn_naive_ = value == "naive";
     else if (key == "qkv2") qkv2_ = value != "0";
     else if (key == "gemm256") gemm256_ = value != "0";
+    else if (key == "ln_fold") ln_fold_ = value != "0";
     else if (key == "tail") tail_ = value != "0";
     else if (key == "latency") latency_ = value != "0";
     else if (key == "stage_kernel") stage_kernel_ = value != "0";
@@ -381,7 +454,10 @@ bool Engine::ensure_workspace(int t_pad, int n_sentences, std::string &err) {
     return x_.ensure(tp * H * es, err) && qkv_.ensure(tp * 3 * H * es, err) && ctx_.ensure(tp * H * es, err) &&
            y_.ensure(tp * H * es, err) && ff_.ensure(tp * I * es, err) && v32_.ensure((size_t)std::max(128, std::min(t_pad, (latency_tokens_ + 255) / 256 * 256)) * H * 4, err) &&
            d_out_.ensure((size_t)n_sentences * H * 4, err) &&
-           windows_.ensure((size_t)n_sentences * sizeof(int2), err);
+           windows_.ensure((size_t)n_sentences * sizeof(int2), err) &&
+           // (LayerNorm folding, H = 768 route: 2 H / 256 partial (sum, sum of squares) pairs and one finalized float4 per row and LayerNorm)
+           (!(H > 384 && H % 256 == 0) || (ln_stats1_.ensure(tp * (2 * H / 256) * 8, err) && ln_stats2_.ensure(tp * (2 * H / 256) * 8, err) &&
+                                           ln_rows1_.ensure(tp * 16, err) && ln_rows2_.ensure(tp * 16, err)));
 }
 
 template <class F>
@@ -487,14 +563,14 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
     const double Td = (double)T;
 
     auto gemm = [&](const char *name, GemmWeightStore &W, const half_t *A, const float *bias, const half_t *resid,
-                    half_t *C, int epi) {
+                    half_t *C, int epi, const GemmLnFold *ln = nullptr) {
         const bool big = W.mfma_ok && gemm256_ && !gemm_naive_ && gemm256_supported(W.w, t_pad);
         const bool tiled = !big && W.mfma_ok && (!gemm_naive_ || !W.w.naive16);
         // (which kernel family served the mat-mul: reported as "family:<kernel>_<weights>" lines of the profile)
         if (profiling_ && replay_name_.empty())
             families_[std::string("family:") + (big ? "gemm256" : tiled ? "gemm_mfma" : "gemm_naive") + (big || tiled ? (W.w.type == GW_F16 ? "_f16" : "_q4") : "")] += 1;
         timed(name, 2.0 * Td * W.w.N * W.w.K, s, [&] {
-            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s);
+            if (big) launch_gemm256(W.w, A, bias, resid, C, t_pad, epi, s, ln);
             else if (tiled) launch_gemm_mfma(W.w, A, bias, resid, C, t_pad, epi, s);
             else launch_gemm_naive(W.w, A, bias, resid, C, T, epi, s);
         });
@@ -595,7 +671,50 @@ int Engine::eval_packed_device(const int32_t *d_tokens, const int32_t *d_cu, int
             launch_model_kernel(mw, hp_.n_layer, x, ctx, d_cu, B, T, d_windows, n_windows, d_n_windows, nh, d_out, max_len, status_.as<int>(), slots, s);
         });
     }
-    for (int il = 0; !skinny && !one_launch && il < hp_.n_layer; ++il) {
+    // LayerNorm folding (kernels.h GemmLnFold): models whose layers run as gemm256 mat-muls on f16 images (H = 768) keep the
+    // UN-normalised sums u1 (in y) and u2 (in x) and never launch a LayerNorm of their own but the last one; a hidden-state tap
+    // wants the normalised states and takes the plain sequence
+    bool fold = ln_fold_ && gemm256_ && !gemm_naive_ && !skinny && !one_launch && !d_hidden && H > 384 && H % 256 == 0 && ln_rows2_.p;
+    for (int il = 0; fold && il < hp_.n_layer; ++il) {
+        LayerWeights &L = *layers_[il];
+        fold = L.fold_ok && gemm256_supported(L.o.w, t_pad) && gemm256_supported(L.ffo.w, t_pad) && gemm256_supported(L.ffi_fold.w, t_pad) &&
+               gemm256_supported(L.qkv.w, t_pad) && !(qkv2_ && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) &&
+               !(tail_ && layer_tail_supported(L.o.w, L.ffi.w, L.ffo.w));
+    }
+    for (int il = 0; fold && il < hp_.n_layer; ++il) {
+        LayerWeights &L = *layers_[il];
+        const int P = 2 * H / 256;
+        float2 *st1 = ln_stats1_.as<float2>(), *st2 = ln_stats2_.as<float2>();
+        float4 *rows1 = ln_rows1_.as<float4>(), *rows2 = ln_rows2_.as<float4>();
+        GemmLnFold ln;
+        if (il == 0) {
+            // x = LayerNorm(embeddings), materialised by the embedding kernel: the plain projection (4-bit planes where the file has them)
+            const bool planes = L.qkv_q4.w.qs && L.qkv_q4.mfma_ok && gemm256_supported(L.qkv_q4.w, t_pad);
+            gemm("gemm_qkv", planes ? L.qkv_q4 : L.qkv, x, L.qkv_b.as<float>(), nullptr, qkv, EPI_BIAS);
+        } else {
+            // x holds u2 of the layer before: its output LayerNorm rides in the folded weights, the statistics k-step and the row scale
+            ln = GemmLnFold(); ln.flags = GemmLnFold::IN; ln.rows_in = rows2; ln.waug = L.qkv_waug.as<half_t>();
+            gemm("gemm_qkv", L.qkv_fold, x, nullptr, nullptr, qkv, EPI_BIAS, &ln);
+        }
+        timed("attention", att_flops, s, [&] {
+            if (attn_naive_ || !launch_attention_mfma(qkv, d_cu, B, nh, dh, max_len, ctx, s))
+                launch_attention_naive(qkv, d_cu, B, nh, dh, max_len, ctx, s);
+        });
+        // u1 = ctx Wo^T + bo + (x | LayerNorm(u2 of the layer before)) -> y, with its rows' partial statistics
+        ln = GemmLnFold(); ln.flags = GemmLnFold::STATS | (il ? GemmLnFold::RES : 0); ln.stats = st1;
+        ln.rows_res = rows2; ln.gb = L.o_gb.as<unsigned>();
+        gemm("gemm_attn_out", L.o, ctx, L.o_b.as<float>(), x, y, EPI_BIAS_RESID, &ln);
+        timed("ln_rows_finalize", 0.0, s, [&] { launch_ln_rows_finalize(st1, P, t_pad, H, rows1, s); });
+        ln = GemmLnFold(); ln.flags = GemmLnFold::IN; ln.rows_in = rows1; ln.waug = L.ffi_waug.as<half_t>();
+        gemm("gemm_ffn_up", L.ffi_fold, y, nullptr, nullptr, ff, EPI_BIAS_GELU, &ln);
+        // u2 = ff W2^T + b2 + LayerNorm(u1) -> x
+        ln = GemmLnFold(); ln.flags = GemmLnFold::STATS | GemmLnFold::RES; ln.stats = st2; ln.rows_res = rows1; ln.gb = L.ffo_gb.as<unsigned>();
+        gemm("gemm_ffn_down", L.ffo, ff, L.ffo_b.as<float>(), y, x, EPI_BIAS_RESID, &ln);
+        timed("ln_rows_finalize", 0.0, s, [&] { launch_ln_rows_finalize(st2, P, t_pad, H, rows2, s); });
+        if (il + 1 == hp_.n_layer)     // (the pooling reads normalised rows: the one LayerNorm launch of the pass)
+            timed("layernorm", 0.0, s, [&] { launch_layernorm(x, L.ln_out_w.as<float>(), L.ln_out_b.as<float>(), T, H, s); });
+    }
+    for (int il = 0; !fold && !skinny && !one_launch && il < hp_.n_layer; ++il) {
         LayerWeights &L = *layers_[il];
         if (qkv2_ && !gemm_naive_ && !attn_naive_ && L.qkv.mfma_ok && qkv_attention2_supported(L.qkv.w, nh, dh, max_len)) {
             // windows of 128 token slots holding whole sentences: Q|K|V never reach HBM whatever the sentence lengths

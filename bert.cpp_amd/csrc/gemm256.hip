@@ -56,7 +56,18 @@ struct Gemm256Args {
     const void *sc;
     int N, K, n_tiles_n, n_tiles;
     int n_groups;           // feature-tile groups an XCD pair / quad shares the walk with (1: every XCD walks all feature tiles)
+    // ---- LayerNorm folded into its neighbours (LN != 0, kernels.h GemmLnFold): the residual mat-muls write the UN-normalised sum u
+    // and per-row partial statistics, the mat-muls that consume LayerNorm(u) read u itself
+    const float4 *rows_in;  // LN_IN: per row of A {rstd, -mean rstd, -mean, std} of the LayerNorm that produced A's consumer input
+    const half_t *waug;     // LN_IN: [N][16] f16, the weight side of the statistics k-step (columns 0..5: s_hi s_lo s_hi c_hi c_lo c_hi)
+    const float4 *rows_res; // LN_RES: per row of resid {rstd, -mean rstd, ..}: the residual is LayerNorm(resid) rebuilt per element
+    const unsigned *gb;     // LN_RES: per feature (f16 gamma | f16 (beta + bias) << 16) instead of `bias`
+    float2 *stats;          // LN_STATS: [M_pad][stats_p] (sum, sum of squares) of the rounded results per row and 128-feature half
+    int stats_p;
 };
+
+// LN flags of the kernel (bert_hip::GemmLnFold's): what this launch does for the LayerNorms around it
+constexpr int LN_IN = 1, LN_RES = 2, LN_STATS = 4;
 
 }  // namespace
 
@@ -122,8 +133,11 @@ __device__ __forceinline__ void g2_tile_barrier(G2Frag &f) {
 // packed f16 math applies (q - 8) d or q d + m: ~15 VALU + one ds_write_b128 per chunk), into the stage the f16 form fills by
 // LDS-DMA — the activation half still arrives that way.  At an output-tile boundary the pending block is expanded in one go in
 // front of the finished tile's epilogue, so the raw registers are dead while the epilogue needs every register.
-template <int EPI, int WT>
+template <int EPI, int WT, int LN = 0>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
+    static_assert(LN == 0 || WT == GW_F16, "LayerNorm folding runs on f16 images");
+    static_assert(!(LN & LN_IN) || EPI != EPI_BIAS_RESID, "a mat-mul either consumes a folded LayerNorm or produces one's input");
+    static_assert(!(LN & (LN_RES | LN_STATS)) || EPI == EPI_BIAS_RESID, "");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool Q4 = WT != GW_F16;
 
@@ -271,17 +285,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
     // 16-byte row segments and turning it through the staging area was tried: the register allocator spills all sixteen
     // vectors in front of the stores, and landing them by LDS-DMA has to wait behind the stores round by round).
     f16x4 rv[EPI == EPI_BIAS_RESID ? 4 : 1][2][4];
+    // LN_IN: the statistics of this lane's two token rows (rstd kept for the epilogue), the weight side of the statistics k-step;
+    // LN_RES: (rstd, -mean rstd) of the two residual rows
+    [[maybe_unused]] float row_rstd[2] = {1.f, 1.f};
+    [[maybe_unused]] f32x4 row_in[2];
+    [[maybe_unused]] f32x4 row_res[2];
     auto init_loads = [&](int im0, int in0) __attribute__((always_inline)) {
         int l31 = lane & 31, hi = lane >> 5;
         asm volatile("" : "+v"(l31), "+v"(hi));
+        if constexpr (LN & LN_IN) {
+            // (no bias: it sits in the statistics k-step's c column.  The four weight-side fragments go into the dead accumulator
+            // tuples like the bias vectors of the plain form)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 wv = *(const f32x4 *)(p.waug + ((size_t)in0 + wf * 128 + i * 32 + l31) * 16 + 8 * hi);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 b = *(const f32x4 *)(p.bias + in0 + wf * 128 + i * 32 + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = b[e];
+                for (int e = 0; e < 4; ++e) acc[i][0][e] = wv[e];
             }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) row_in[j] = *(const f32x4 *)(p.rows_in + (size_t)im0 + wq * 64 + j * 32 + l31);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // (LN_RES: the same place holds the packed (gamma, beta + bias) pairs of the features)
+                    const f32x4 b = (LN & LN_RES) ? *(const f32x4 *)(p.gb + in0 + wf * 128 + i * 32 + 8 * g + 4 * hi)
+                                                  : *(const f32x4 *)(p.bias + in0 + wf * 128 + i * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][0][4 * g + e] = b[e];
+                }
+        }
         if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -290,10 +324,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) rv[i][j][g] = *(const f16x4 *)(rrow + i * 32 + 8 * g);
+                if constexpr (LN & LN_RES) row_res[j] = *(const f32x4 *)(p.rows_res + (size_t)im0 + wq * 64 + j * 32 + l31);
             }
         }
     };
     auto init_acc = [&]() __attribute__((always_inline)) {
+        if constexpr (LN & LN_IN) {
+            // the statistics k-step: acc = sum_k W'[n][k] u[t][k] will get  - mean_t s[n] + std_t c[n]  from ONE MFMA per block
+            // (hi / lo f16 pairs on both sides: 2^-21 relative), and the epilogue multiplies by rstd_t:
+            //     rstd (W' u - mean s) + c  =  W (gamma (u - mean) rstd + beta) + bias
+            int hi = lane >> 5;
+            asm volatile("" : "+v"(hi));
+            f16x8 wa[4], ta[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 wv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wv[e] = acc[i][0][e];
+                wa[i] = __builtin_bit_cast(f16x8, wv);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                row_rstd[j] = row_in[j][0];
+                const float nm = row_in[j][2], sd = row_in[j][3];
+                const _Float16 nm_h = (_Float16)nm, sd_h = (_Float16)sd;
+                const _Float16 nm_l = (_Float16)(nm - (float)nm_h), sd_l = (_Float16)(sd - (float)sd_h), z = (_Float16)0.f;
+                const f16x8 t = {nm_h, nm_h, nm_l, sd_h, sd_h, sd_l, z, z};
+                ta[j] = hi ? (f16x8)z : t;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[i], ta[j], (f32x16)0.f, 0, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -301,7 +365,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float b = acc[i][0][4 * g + e];
-                    if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
+                    if constexpr ((LN & LN_RES) != 0) {
+                        // residual = LayerNorm(resid) rebuilt per element: gamma ((r - mean) rstd) + beta, + bias
+                        const unsigned w = __builtin_bit_cast(unsigned, b);
+                        const float gm = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xffffu));
+                        const float bb = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+                        acc[i][1][4 * g + e] = __builtin_fmaf(gm, __builtin_fmaf((float)rv[i][1][g][e], row_res[1][0], row_res[1][1]), bb);
+                        acc[i][0][4 * g + e] = __builtin_fmaf(gm, __builtin_fmaf((float)rv[i][0][g][e], row_res[0][0], row_res[0][1]), bb);
+                    } else if (EPI == EPI_BIAS_RESID && !(G2_ABLATE & 4)) {
                         acc[i][1][4 * g + e] = b + (float)rv[i][1][g][e];
                         acc[i][0][4 * g + e] = b + (float)rv[i][0][g][e];
                     } else {
@@ -334,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
         // registers that are free hold no 4-register run for the next tile's bias vectors — sixteen of them were spilled.
         typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
         u32x16 o16[4];
+        [[maybe_unused]] float st1[2] = {0.f, 0.f}, st2[2] = {0.f, 0.f};      // LN_STATS: this lane's (sum, sum of squares) per token block
 #pragma unroll
         for (int ip = 0; ip < 2; ++ip)
 #pragma unroll
@@ -343,20 +415,40 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x16 &a = acc[2 * ip + ii][j];
+                        const float rs = (LN & LN_IN) ? row_rstd[j] : 1.f;      // (LN_IN: the row's 1 / std, see init_acc)
                         f16x4 h;
                         if (EPI == EPI_BIAS_GELU) {
                             // packed f16, as layer_tail.hip evaluates it (the reference reads the GELU from an f16 table)
-                            const f16x2_t g0 = gelu_pk16(a[4 * g], a[4 * g + 1]), g1 = gelu_pk16(a[4 * g + 2], a[4 * g + 3]);
+                            const f16x2_t g0 = (LN & LN_IN) ? gelu_pk16(a[4 * g] * rs, a[4 * g + 1] * rs) : gelu_pk16(a[4 * g], a[4 * g + 1]);
+                            const f16x2_t g1 = (LN & LN_IN) ? gelu_pk16(a[4 * g + 2] * rs, a[4 * g + 3] * rs) : gelu_pk16(a[4 * g + 2], a[4 * g + 3]);
                             h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
                             __builtin_amdgcn_sched_barrier(0);   // one run at a time: the GELU temporaries of several would spill
                         } else {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) h[e] = (_Float16)a[4 * g + e];
+                            for (int e = 0; e < 4; ++e) h[e] = (LN & LN_IN) ? (_Float16)rounded_f32(a[4 * g + e] * rs) : (_Float16)a[4 * g + e];
+                        }
+                        if constexpr ((LN & LN_STATS) != 0) {
+                            // (of the ROUNDED values: what the consumers of u read)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float hv = (float)h[e]; st1[j] += hv; st2[j] = __builtin_fmaf(hv, hv, st2[j]); }
                         }
                         const uint2 hb = __builtin_bit_cast(uint2, h);
                         o16[ip * 2 + j][(ii * 4 + g) * 2] = hb.x;
                         o16[ip * 2 + j][(ii * 4 + g) * 2 + 1] = hb.y;
                     }
+        if constexpr ((LN & LN_STATS) != 0) {
+            // the two lane halves hold the two 4-feature runs of every 8: one partial per (row, 128-feature half of the tile)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                st1[j] += __shfl_xor(st1[j], 32);
+                st2[j] += __shfl_xor(st2[j], 32);
+            }
+            if (hi == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    p.stats[((size_t)em0 + wq * 64 + j * 32 + l31) * p.stats_p + (en0 / G2_BN) * 2 + wf] = make_float2(st1[j], st2[j]);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // the next tile's initial values: every load of the tile boundary is issued here, in front of the first store (vmcnt
         // retires in issue order: a load behind a store would wait for that store's acknowledgement) and BEHIND phase 1 (the
@@ -510,9 +602,11 @@ bool gemm256_supported(const GemmWeight &W, int M_pad) {
 }
 
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream) {
+                    int epilogue, hipStream_t stream, const GemmLnFold *ln) {
     Gemm256Args a;
     a.A = A; a.w16 = W.w16; a.bias = bias; a.resid = resid; a.C = C; a.qs = W.qs; a.sc = W.sc;
+    a.rows_in = ln ? ln->rows_in : nullptr; a.waug = ln ? ln->waug : nullptr; a.rows_res = ln ? ln->rows_res : nullptr;
+    a.gb = ln ? ln->gb : nullptr; a.stats = ln ? ln->stats : nullptr; a.stats_p = 2 * (W.N / G2_BN);
     a.N = W.N; a.K = W.K; a.n_tiles_n = W.N / G2_BN;
     a.n_tiles = a.n_tiles_n * (M_pad / G2_BM);
     // feature groups: only where W (N x K f16) overflows an XCD's L2 share and reading the activations twice is the cheaper
@@ -532,7 +626,7 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
     const int cus = dev >= 0 && dev < MAX_HIP_DEVICES ? n_cu[dev] : 256;
     const int grid = std::min(cus, (a.n_tiles + 7) / 8 * 8);
     const size_t lds = 2 * G2_STAGE + 8 * 4096;        // 128 KiB of reduction tiles + 8 wave-private staging areas
-    static DeviceFlags configured[9];
+    static DeviceFlags configured[13];
     auto go = [&](auto kernel, int e) {
         configure_once(configured[e], [&] { (void)hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         BERT_LAUNCH(kernel, dim3(grid), dim3(512), lds, stream, a);
@@ -545,6 +639,15 @@ void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, con
             default: go(gemm256_kernel<E, GW_Q4_1>, 6 + E); break;
         }
     };
+    if (ln && ln->flags && W.type == GW_F16) {
+        // (the folded-LayerNorm forms: f16 images only — the engine does not fold where a matrix stays on 4-bit planes)
+        if (epilogue == EPI_BIAS && ln->flags == GemmLnFold::IN) go(gemm256_kernel<EPI_BIAS, GW_F16, LN_IN>, 9);
+        else if (epilogue == EPI_BIAS_GELU && ln->flags == GemmLnFold::IN) go(gemm256_kernel<EPI_BIAS_GELU, GW_F16, LN_IN>, 10);
+        else if (epilogue == EPI_BIAS_RESID && ln->flags == GemmLnFold::STATS) go(gemm256_kernel<EPI_BIAS_RESID, GW_F16, LN_STATS>, 11);
+        else if (epilogue == EPI_BIAS_RESID && ln->flags == (GemmLnFold::RES | GemmLnFold::STATS)) go(gemm256_kernel<EPI_BIAS_RESID, GW_F16, LN_RES | LN_STATS>, 12);
+        else fprintf(stderr, "launch_gemm256: unsupported LayerNorm-folding form (epilogue %d, flags %d): nothing launched\n", epilogue, ln->flags);
+        return;
+    }
     switch (epilogue) {
         case EPI_BIAS: by_type(std::integral_constant<int, EPI_BIAS>{}); break;
         case EPI_BIAS_GELU: by_type(std::integral_constant<int, EPI_BIAS_GELU>{}); break;

@@ -183,8 +183,25 @@ void launch_gemm_mfma(const GemmWeight &W, const half_t *A, const float *bias, c
                       int M_pad, int epilogue, hipStream_t stream);
 // Large-tile variant (gemm256.hip): 256 x 256 x 64 tiles, 8 waves; f16 weights, N % 256 == 0, M_pad % 256 == 0.
 bool gemm256_supported(const GemmWeight &W, int M_pad);
+// LayerNorm folded into the mat-muls around it (H = 768 route; reference bert.cpp:866-875, :892-901 have it as operations of their
+// own): a residual mat-mul writes the UN-normalised sum u (f16) and per-row partial statistics of it (STATS); ln_rows_finalize turns
+// those into {rstd, -mean rstd, -mean, std} per row; a mat-mul that consumes LayerNorm(u) reads u itself with gamma folded into its
+// weights and ONE extra k-step that carries - mean s[n] + std c[n] (s = row sums of the folded weights, c = W beta + bias), its
+// epilogue multiplying by rstd (IN); a residual mat-mul whose residual is LayerNorm(u) rebuilds it per element from u, the row
+// statistics and packed (gamma, beta + bias) pairs (RES).  f16 images only.
+struct GemmLnFold {
+    enum : int { IN = 1, RES = 2, STATS = 4 };
+    int flags = 0;
+    const float4 *rows_in = nullptr;      // IN: statistics of A's rows
+    const half_t *waug = nullptr;         // IN: [N][16] f16 weight side of the statistics k-step
+    const float4 *rows_res = nullptr;     // RES: statistics of resid's rows
+    const unsigned *gb = nullptr;         // RES: [N] f16 gamma | f16 (beta + bias) << 16
+    float2 *stats = nullptr;              // STATS: [M_pad][2 N / 256] (sum, sum of squares)
+};
 void launch_gemm256(const GemmWeight &W, const half_t *A, const float *bias, const half_t *resid, half_t *C, int M_pad,
-                    int epilogue, hipStream_t stream);
+                    int epilogue, hipStream_t stream, const GemmLnFold *ln = nullptr);
+// per-row partial statistics [T][P] -> {rstd, -mean rstd, -mean, std} (eps 1e-5, H features per row)
+void launch_ln_rows_finalize(const float2 *stats, int P, int T, int H, float4 *rows, hipStream_t stream);
 // Out-projection + LN + FFN + LN in one launch (layer_tail.hip): a pair of specialist waves per 32 tokens (up-projection +
 // GELU / down-projection); H = 256 / 384; f16 weights (W1 / W2 need w16p) or q4 planes.
 bool layer_tail_supported(const GemmWeight &Wo, const GemmWeight &W1, const GemmWeight &W2);

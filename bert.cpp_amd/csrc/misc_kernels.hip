@@ -343,6 +343,23 @@ void launch_layernorm(half_t *x, const float *gamma, const float *beta, int T, i
     else BERT_LAUNCH(layernorm_kernel<32>, grid, block, 0, stream, x, gamma, beta, T, H);   // H <= 4096
 }
 
+// LayerNorm folded into the H = 768 mat-muls (kernels.h GemmLnFold): the residual mat-mul's epilogue left P partial (sum, sum of
+// squares) pairs per row; the row's {1 / std, - mean / std, - mean, std} (eps 1e-5) for the mat-muls that read the un-normalised rows
+__global__ __launch_bounds__(256) void ln_rows_finalize_kernel(const float2 *__restrict__ stats, int P, int T, float inv_h, float4 *__restrict__ rows) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < P; ++p) { const float2 v = stats[(size_t)t * P + p]; s1 += v.x; s2 += v.y; }
+    const float mean = s1 * inv_h, var = fmaxf(s2 * inv_h - mean * mean, 0.f) + 1e-5f;
+    const float sd = sqrtf(var), rstd = 1.0f / sd;
+    rows[t] = make_float4(rstd, -mean * rstd, -mean, sd);
+}
+
+void launch_ln_rows_finalize(const float2 *stats, int P, int T, int H, float4 *rows, hipStream_t stream) {
+    if (T <= 0) return;
+    BERT_LAUNCH(ln_rows_finalize_kernel, dim3((T + 255) / 256), dim3(256), 0, stream, stats, P, T, 1.0f / H, rows);
+}
+
 // reference bert.cpp:904-913: mean over all N tokens (mat-vec with a 1/N vector), then y / ||y||_2.
 // One workgroup per sentence (pool_normalize.h: the body, shared with the epilogue of model_kernel.hip).
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const half_t *x, const int32_t *cu_seqlens, int H,

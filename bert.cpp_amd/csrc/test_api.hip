@@ -54,6 +54,60 @@ int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint16_t *A, c
     return 0;
 }
 
+int32_t bert_hip_test_gemm_lnfold(int32_t M, int32_t K1, int32_t H, int32_t N2, const uint16_t *A1, const uint16_t *W1, const float *b1,
+                                  const uint16_t *r, const float *rg, const float *rb, const uint16_t *W2, const float *b2, const float *g,
+                                  const float *be, int32_t epi2, uint16_t *u_out, uint16_t *out2, float *rows_out) {
+    std::string err;
+    auto tensor = [](const uint16_t *w, int n, int k) {
+        HostTensor t;
+        t.type = W_F16; t.n_dims = 2; t.ne0 = k; t.ne1 = n; t.data = (const uint8_t *)w; t.nbytes = (size_t)n * k * 2;
+        return t;
+    };
+    const HostTensor t1 = tensor(W1, H, K1), t2 = tensor(W2, N2, H);
+    GemmWeightStore w1, w2;
+    DevBuf waug, gb;
+    if (!w1.build({&t1}, false, err) || !w2.build_ln_fold({&t2}, g, be, b2, waug, err)) { fprintf(stderr, "bert_hip_test_gemm_lnfold: %s\n", err.c_str()); return -1; }
+    const int M_pad = (M + 255) / 256 * 256, P = 2 * H / 256;
+    if (!gemm256_supported(w1.w, M_pad) || !gemm256_supported(w2.w, M_pad) || H % 256) return -2;
+    DevBuf dA, dB1, dR, dU, dOut, dStats, dRows, dRowsRes;
+    if (!dA.alloc((size_t)M_pad * K1 * 2, err) || !dB1.upload(b1, (size_t)H * 4, err) || !dR.alloc((size_t)M_pad * H * 2, err) || !dU.alloc((size_t)M_pad * H * 2, err) ||
+        !dOut.alloc((size_t)M_pad * N2 * 2, err) || !dStats.alloc((size_t)M_pad * P * 8, err) || !dRows.alloc((size_t)M_pad * 16, err) || !dRowsRes.alloc((size_t)M_pad * 16, err)) return -1;
+    CK(hipMemcpy(dA.p, A1, (size_t)M * K1 * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dR.p, r, (size_t)M * H * 2, hipMemcpyHostToDevice));
+    GemmLnFold ln;
+    ln.flags = GemmLnFold::STATS; ln.stats = dStats.as<float2>();
+    if (rg) {
+        // the residual's own row statistics (what the mat-mul that produced r would have left behind), and the packed (gamma, beta + bias)
+        std::vector<float> rows((size_t)M_pad * 4, 0.f);
+        for (int t = 0; t < M; ++t) {
+            double s1 = 0, s2 = 0;
+            for (int f = 0; f < H; ++f) { _Float16 h; memcpy(&h, &r[(size_t)t * H + f], 2); s1 += (double)(float)h; s2 += (double)(float)h * (double)(float)h; }
+            const double mean = s1 / H, var = std::max(s2 / H - mean * mean, 0.0) + 1e-5, sd = std::sqrt(var);
+            rows[4 * (size_t)t] = (float)(1.0 / sd); rows[4 * (size_t)t + 1] = (float)(-mean / sd); rows[4 * (size_t)t + 2] = (float)-mean; rows[4 * (size_t)t + 3] = (float)sd;
+        }
+        CK(hipMemcpy(dRowsRes.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
+        std::vector<uint32_t> v((size_t)H);
+        for (int f = 0; f < H; ++f) {
+            const _Float16 gg = (_Float16)rg[f], bb = (_Float16)(rb[f] + b1[f]);
+            uint16_t gu, bu; memcpy(&gu, &gg, 2); memcpy(&bu, &bb, 2);
+            v[(size_t)f] = (uint32_t)gu | ((uint32_t)bu << 16);
+        }
+        if (!gb.upload(v.data(), v.size() * 4, err)) return -1;
+        ln.flags |= GemmLnFold::RES; ln.rows_res = dRowsRes.as<float4>(); ln.gb = gb.as<unsigned>();
+    }
+    launch_gemm256(w1.w, dA.as<half_t>(), dB1.as<float>(), dR.as<half_t>(), dU.as<half_t>(), M_pad, EPI_BIAS_RESID, nullptr, &ln);
+    launch_ln_rows_finalize(dStats.as<float2>(), P, M_pad, H, dRows.as<float4>(), nullptr);
+    GemmLnFold in;
+    in.flags = GemmLnFold::IN; in.rows_in = dRows.as<float4>(); in.waug = waug.as<half_t>();
+    launch_gemm256(w2.w, dU.as<half_t>(), nullptr, nullptr, dOut.as<half_t>(), M_pad, epi2, nullptr, &in);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(u_out, dU.p, (size_t)M * H * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(out2, dOut.p, (size_t)M * N2 * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(rows_out, dRows.p, (size_t)M * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head, int32_t d_head,
                                 const uint16_t *qkv, int32_t impl, uint16_t *out) {
     std::string err;

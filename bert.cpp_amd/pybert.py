@@ -28,7 +28,7 @@ BERT_HIP_H_SYMBOLS = [
 ]
 # include/bert_hip_test.h: the op-level test hooks, exported by libbert_test.so only
 BERT_HIP_TEST_H_SYMBOLS = [
-    "bert_hip_test_gemm", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
+    "bert_hip_test_gemm", "bert_hip_test_gemm_lnfold", "bert_hip_test_attention", "bert_hip_test_qkv_attention",
     "bert_hip_test_layer_tail", "bert_hip_test_shard_bounds", "bert_hip_test_build_windows",
     "bert_hip_test_build_windows_device", "bert_hip_test_max_windows", "bert_hip_test_set_window_slots",
     "bert_hip_test_dispatch", "bert_hip_test_shard_threads_created", "bert_hip_test_embed_ln", "bert_hip_test_pool_normalize",
@@ -113,6 +113,8 @@ def test_lib() -> C.CDLL:
     vp, i32, i32p = C.c_void_p, C.c_int32, C.POINTER(C.c_int32)
     L.bert_hip_test_gemm.restype = i32
     L.bert_hip_test_gemm.argtypes = [i32, i32, i32, vp, vp, i32, vp, vp, i32, i32, vp]
+    L.bert_hip_test_gemm_lnfold.restype = i32
+    L.bert_hip_test_gemm_lnfold.argtypes = [i32, i32, i32, i32] + [vp] * 10 + [i32, vp, vp, vp]
     L.bert_hip_test_attention.restype = i32
     L.bert_hip_test_attention.argtypes = [i32, i32p, i32, i32, vp, i32, vp]
     L.bert_hip_test_qkv_attention.restype = i32
@@ -401,6 +403,23 @@ def test_gemm(A: np.ndarray, W_bytes: np.ndarray, wtype: int, N: int, bias: np.n
     if r != 0:
         raise RuntimeError(f"bert_hip_test_gemm failed: {r}")
     return out
+
+
+def test_gemm_lnfold(A1, W1, b1, r, rg, rb, W2, b2, g, be, epi2):
+    """The LayerNorm-folded mat-mul pair of the H = 768 route (include/bert_hip_test.h): returns (u [M,H] f16, out2 [M,N2] f16, rows [M,4] f32)."""
+    L = test_lib()
+    A1 = np.ascontiguousarray(A1, dtype=np.float16); W1 = np.ascontiguousarray(W1, dtype=np.float16); W2 = np.ascontiguousarray(W2, dtype=np.float16)
+    r = np.ascontiguousarray(r, dtype=np.float16)
+    f = lambda v: None if v is None else np.ascontiguousarray(v, dtype=np.float32)
+    b1, rg, rb, b2, g, be = f(b1), f(rg), f(rb), f(b2), f(g), f(be)
+    M, K1 = A1.shape
+    H, N2 = W1.shape[0], W2.shape[0]
+    u = np.zeros((M, H), dtype=np.float16); out = np.zeros((M, N2), dtype=np.float16); rows = np.zeros((M, 4), dtype=np.float32)
+    p = lambda v: None if v is None else v.ctypes.data
+    rc = L.bert_hip_test_gemm_lnfold(M, K1, H, N2, p(A1), p(W1), p(b1), p(r), p(rg), p(rb), p(W2), p(b2), p(g), p(be), epi2, p(u), p(out), p(rows))
+    if rc != 0:
+        raise RuntimeError(f"bert_hip_test_gemm_lnfold failed: {rc}")
+    return u, out, rows
 
 
 def test_attention(qkv: np.ndarray, cu_seqlens: np.ndarray, n_head: int, d_head: int, impl: int) -> np.ndarray:

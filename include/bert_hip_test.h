@@ -20,6 +20,18 @@ BERT_API int32_t bert_hip_test_gemm(int32_t M, int32_t N, int32_t K, const uint1
                                     int32_t wtype, const float *bias, const uint16_t *resid,
                                     int32_t epilogue, int32_t impl, uint16_t *C);
 
+/* LayerNorm folded into the mat-muls around it (kernels.h GemmLnFold; gemm256.hip, f16 weights, H and N2 multiples of 256, M is
+ * padded to 256): the pair a layer runs —
+ *   u   = A1[M][K1] W1[H][K1]^T + b1 + R,   R = r[M][H] itself (rg == NULL) or LayerNorm(r; rg, rb) rebuilt per element from r's row
+ *         statistics (computed here on the host), written UN-normalised with per-row partial statistics;
+ *   out = epi2( LayerNorm(u; g, be) W2[N2][H]^T + b2 ),  epi2 0 = bias, 1 = bias + GELU: reads u itself, gamma folded into W2, one
+ *         statistics k-step, rows scaled by 1 / std.
+ * u_out [M][H], out2 [M][N2] f16 bits, rows_out [M][4] f32 {rstd, -mean rstd, -mean, std} of u.  Returns 0 on success.          */
+BERT_API int32_t bert_hip_test_gemm_lnfold(int32_t M, int32_t K1, int32_t H, int32_t N2, const uint16_t *A1, const uint16_t *W1,
+                                           const float *b1, const uint16_t *r, const float *rg, const float *rb,
+                                           const uint16_t *W2, const float *b2, const float *g, const float *be, int32_t epi2,
+                                           uint16_t *u_out, uint16_t *out2, float *rows_out);
+
 /* qkv[T][3H] f16 bits (Q | K | V per row), packed sentences -> ctx[T][H] f16 bits.             */
 BERT_API int32_t bert_hip_test_attention(int32_t n_sentences, const int32_t *cu_seqlens, int32_t n_head,
                                          int32_t d_head, const uint16_t *qkv, int32_t impl, uint16_t *out);

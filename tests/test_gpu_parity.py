@@ -120,6 +120,49 @@ def test_gemm256_q4_tile_load_gives_the_f16_form_s_bits(M, N, K, wtype):
     assert not (err > 2e-3 * np.abs(base) + 6e-3).any(), float(err.max())
 
 
+@pytest.mark.parametrize("rebuild", [False, True], ids=["plain-residual", "rebuilt-residual"])
+@pytest.mark.parametrize("M,K1,H,N2,epi2", [(300, 768, 768, 3072, 1), (1000, 3072, 768, 2304, 0), (20000, 256, 768, 768, 1), (257, 128, 256, 512, 0)])
+def test_layernorm_folded_into_the_gemms(M, K1, H, N2, epi2, rebuild):
+    """The H = 768 route's LayerNorms live inside the mat-muls around them (kernels.h GemmLnFold; reference bert.cpp:866-875, :892-901):
+    a residual mat-mul writes the UN-normalised sum u and per-row partial statistics of its rounded values — its own residual plain, or
+    LayerNorm(r) REBUILT per element from r, r's row statistics and packed (gamma, beta + bias) —; the mat-mul that consumes
+    LayerNorm(u) reads u itself: gamma folded into its weights, ONE extra k-step carrying - mean s[n] + std c[n] (hi / lo f16 pairs),
+    rows scaled by 1 / std in the epilogue.  Against float64 on the same f16 inputs: u, the row statistics, and
+    epi(LayerNorm(u) W2^T + b2) (bias, bias + GELU) — with shifted rows (mean != 0), feature-dependent gamma / beta, several output
+    tiles per workgroup."""
+    rng = np.random.default_rng(M + K1 + N2 + rebuild)
+    A1 = rng.normal(0, 1, (M, K1)).astype(np.float16)
+    W1 = (rng.normal(0, 1, (H, K1)) / np.sqrt(K1)).astype(np.float16)
+    b1 = rng.normal(0, 0.3, H).astype(np.float32)
+    r = (rng.normal(0, 1, (M, H)) + rng.normal(0, 0.7, (M, 1))).astype(np.float16)        # (rows with a mean of their own)
+    rg = (1 + rng.normal(0, 0.2, H)).astype(np.float32); rb = rng.normal(0, 0.2, H).astype(np.float32)
+    W2 = (rng.normal(0, 1, (N2, H)) / np.sqrt(H)).astype(np.float16)
+    b2 = rng.normal(0, 0.5, N2).astype(np.float32)
+    g = (1 + rng.normal(0, 0.2, H)).astype(np.float32); be = rng.normal(0, 0.3, H).astype(np.float32)
+
+    def ln(v, gamma, beta):
+        v = v.astype(np.float64)
+        mu = v.mean(axis=1, keepdims=True)
+        var = ((v - mu) ** 2).mean(axis=1, keepdims=True)
+        return (v - mu) / np.sqrt(var + 1e-5) * gamma + beta
+
+    u, out, rows = pybert.test_gemm_lnfold(A1, W1, b1, r, rg if rebuild else None, rb if rebuild else None, W2, b2, g, be, epi2)
+    resid = ln(r, rg, rb) if rebuild else r.astype(np.float64)
+    u_ref = A1.astype(np.float64) @ W1.astype(np.float64).T + b1 + resid
+    err = np.abs(u.astype(np.float64) - u_ref)
+    assert not (err > 2e-3 * np.abs(u_ref) + 6e-3).any(), ("u", float(err.max()))
+    # the statistics are those of the ROUNDED u (what the consumer reads)
+    uf = u.astype(np.float64)
+    mu, sd = uf.mean(axis=1), np.sqrt(uf.var(axis=1) + 1e-5)
+    assert np.abs(rows[:, 3] - sd).max() < 2e-5 * sd.max() + 1e-6 and np.abs(-rows[:, 2] - mu).max() < 1e-5
+    assert np.allclose(rows[:, 0] * rows[:, 3], 1, atol=1e-6) and np.allclose(rows[:, 1], rows[:, 2] * rows[:, 0], atol=1e-6)
+    base = ln(u, g, be) @ W2.astype(np.float64).T + b2
+    want = _gelu(base) if epi2 == 1 else base
+    err = np.abs(out.astype(np.float64) - want)
+    assert not (err > 3e-3 * np.abs(want) + 8e-3).any(), ("out", float(err.max()), np.argwhere(err > 3e-3 * np.abs(want) + 8e-3)[:5].tolist())
+    assert err.mean() < 6e-4, float(err.mean())
+
+
 @pytest.mark.parametrize("M,H,I", [(200, 128, 256), (256, 256, 512), (130, 384, 1536), (384, 384, 256), (128, 128, 128), (1000, 256, 1024)])
 def test_layer_tail_kernel(M, H, I, impl=1):
     """Out-projection + LN + FFN + LN in one launch (layer_tail.hip) and as five kernels (three GEMMs, two LayerNorms: the
@@ -952,7 +995,7 @@ def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
 _FULL_SIZE_OUT = {}       # (config, q4 mode) -> embeddings: the fused run is compared with the default's bits
 
 
-@pytest.mark.parametrize("q4", ["expand", "fused"])
+@pytest.mark.parametrize("q4", ["expand", "expand-plain-layernorm", "fused"])
 def test_full_size_batch_properties_bert_base(make_model, q4, monkeypatch):
     """configs[3] at full size: bert-base dims q4_1, 512 sentences of 512 tokens.  Unit norm, duplicates give identical
     bits wherever they sit, the kernels the H = 768 path is meant to use are the ones that ran, and eight sentences spread
@@ -960,8 +1003,15 @@ def test_full_size_batch_properties_bert_base(make_model, q4, monkeypatch):
     default) and as BASELINE.json writes the config — 4-bit in HBM, dequantised in gemm256's tile load (kernel family
     asserted: every weight mat-mul of the pass ran on gemm256 with q4 planes) — with EQUAL BITS between the two."""
     path, hp = make_model("bert-base", "q4_1", 0)
+    # (the default folds the H = 768 LayerNorms into the mat-muls around them — kernels.h GemmLnFold; "expand-plain-layernorm": the
+    # LayerNorm kernels of their own, the arithmetic the 4-bit-planes form shares bit for bit)
+    plain_ln = q4 == "expand-plain-layernorm"
+    q4 = q4.split("-")[0]
     monkeypatch.setenv("BERT_HIP_Q4", q4)
+    if plain_ln:
+        monkeypatch.setenv("BERT_HIP_LN_FOLD", "0")
     m = pybert.BertModel(path)
+    folded = q4 == "expand" and not plain_ln
     B, N = 512, 512
     ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 3)
     ids[B // 2] = ids[3]
@@ -973,14 +1023,23 @@ def test_full_size_batch_properties_bert_base(make_model, q4, monkeypatch):
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention", "layernorm"} <= set(rep), sorted(rep)
     fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
-    # (default: the Q | K | V mat-mul runs on the 4-bit planes too — its f16 image does not fit an XCD's L2 — the other three on f16 images)
-    assert fam == ({"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}), fam
+    # (plain LayerNorms: the Q | K | V mat-mul runs on the 4-bit planes too — its f16 image does not fit an XCD's L2 — the other three on
+    # f16 images; folded: only the first layer's, whose input the embedding kernel normalised, the later ones on the folded f16 image)
+    want_fam = {"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else \
+               {"family:gemm256_q4": 1, "family:gemm256_f16": 4 * hp.n_layer - 1} if folded else \
+               {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}
+    assert fam == want_fam, fam
+    # (folded: ONE LayerNorm launch per pass — the last layer's, for the pooling — and a row-statistics launch per LayerNorm)
+    assert rep["layernorm"]["launches"] == (1 if folded else 2 * hp.n_layer), rep["layernorm"]
+    assert ("ln_rows_finalize" in rep) == folded and (not folded or rep["ln_rows_finalize"]["launches"] == 2 * hp.n_layer)
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
-    _FULL_SIZE_OUT[("bert-base", q4)] = out
-    if q4 == "fused" and ("bert-base", "expand") in _FULL_SIZE_OUT:
-        assert np.array_equal(out, _FULL_SIZE_OUT[("bert-base", "expand")])
+    _FULL_SIZE_OUT[("bert-base", q4, plain_ln)] = out
+    if q4 == "fused" and ("bert-base", "expand", True) in _FULL_SIZE_OUT:
+        assert np.array_equal(out, _FULL_SIZE_OUT[("bert-base", "expand", True)])
+    if folded and ("bert-base", "expand", True) in _FULL_SIZE_OUT:        # (folding changes roundings, not values)
+        assert min(cosine(a, b) for a, b in zip(out[::17], _FULL_SIZE_OUT[("bert-base", "expand", True)][::17])) > 1 - 2e-6
     o = orc.Oracle(path)
     sample = [0, 3, 77, B // 3, B // 2 + 5, 400, B - 2, B - 1]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
@@ -1025,14 +1084,19 @@ def test_full_size_batch_properties(make_model, ftype, B, q4, monkeypatch):
     assert min(cosine(out[i], o.eval(ids[i], orc.MODE_PLAIN)) for i in sample) >= TIGHT_COS_PLAIN
 
 
-@pytest.mark.parametrize("q4", ["expand", "fused"])
+@pytest.mark.parametrize("q4", ["expand", "expand-plain-layernorm", "fused"])
 def test_full_size_batch_properties_mpnet_dims(make_model, q4, monkeypatch):
     """configs[4]'s model (BERT architecture at mpnet-base dimensions, q4_0), 1024 sentences of 128 tokens.  Unit norm,
     duplicates give identical bits, the H = 768 kernel family ran (with BERT_HIP_Q4=fused: on 4-bit planes, equal bits with
     the default), and six sentences spread over the batch agree with both oracle modes."""
     path, hp = make_model("mpnet-dims", "q4_0", 0)
+    plain_ln = q4 == "expand-plain-layernorm"
+    q4 = q4.split("-")[0]
     monkeypatch.setenv("BERT_HIP_Q4", q4)
+    if plain_ln:
+        monkeypatch.setenv("BERT_HIP_LN_FOLD", "0")
     m = pybert.BertModel(path)
+    folded = q4 == "expand" and not plain_ln
     B, N = 1024, 128
     ids = gf.synthetic_token_ids(B, N, hp.n_vocab, seed=1234 + 4)
     ids[B // 2] = ids[3]
@@ -1044,13 +1108,19 @@ def test_full_size_batch_properties_mpnet_dims(make_model, q4, monkeypatch):
     m.profile(False)
     assert {"gemm_qkv", "gemm_ffn_up", "gemm_ffn_down", "gemm_attn_out", "attention"} <= set(rep), sorted(rep)
     fam = {k: v["launches"] for k, v in rep.items() if k.startswith("family:")}
-    assert fam == ({"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}), fam
+    want_fam = {"family:gemm256_q4": 4 * hp.n_layer} if q4 == "fused" else \
+               {"family:gemm256_q4": 1, "family:gemm256_f16": 4 * hp.n_layer - 1} if folded else \
+               {"family:gemm256_q4": hp.n_layer, "family:gemm256_f16": 3 * hp.n_layer}
+    assert fam == want_fam, fam
+    assert rep["layernorm"]["launches"] == (1 if folded else 2 * hp.n_layer), rep["layernorm"]
     assert np.isfinite(out).all()
     assert np.abs(np.linalg.norm(out, axis=1) - 1).max() < 1e-3
     assert np.array_equal(out[3], out[B // 2]) and np.array_equal(out[3], out[B - 1])
-    _FULL_SIZE_OUT[("mpnet-dims", q4)] = out
-    if q4 == "fused" and ("mpnet-dims", "expand") in _FULL_SIZE_OUT:
-        assert np.array_equal(out, _FULL_SIZE_OUT[("mpnet-dims", "expand")])
+    _FULL_SIZE_OUT[("mpnet-dims", q4, plain_ln)] = out
+    if q4 == "fused" and ("mpnet-dims", "expand", True) in _FULL_SIZE_OUT:
+        assert np.array_equal(out, _FULL_SIZE_OUT[("mpnet-dims", "expand", True)])
+    if folded and ("mpnet-dims", "expand", True) in _FULL_SIZE_OUT:
+        assert min(cosine(a, b) for a, b in zip(out[::17], _FULL_SIZE_OUT[("mpnet-dims", "expand", True)][::17])) > 1 - 2e-6
     o = orc.Oracle(path)
     sample = [0, 3, B // 3, B // 2 + 5, B - 2, B - 1]
     coss = [cosine(out[i], o.eval(ids[i], orc.MODE_GGML)) for i in sample]
