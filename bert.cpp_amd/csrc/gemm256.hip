@@ -73,6 +73,9 @@ constexpr int LN_IN = 1, LN_RES = 2, LN_STATS = 4;
 
 // G2_ABLATE (tuning builds only, results are wrong): bit 0 no global stores in the epilogue, bit 1 no epilogue at all,
 // bit 2 no residual loads, bit 3 no LDS staging (the stores write whatever the staging area holds) — what a component costs is the time its removal saves (tools/variant.sh)
+#ifndef G2_GELU_RUNS
+#define G2_GELU_RUNS 1      // GELU runs of 4 values the scheduler may interleave in the epilogue
+#endif
 #ifndef G2_ABLATE
 #define G2_ABLATE 0
 #endif
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
                             const f16x2_t g0 = (LN & LN_IN) ? gelu_pk16(a[4 * g] * rs, a[4 * g + 1] * rs) : gelu_pk16(a[4 * g], a[4 * g + 1]);
                             const f16x2_t g1 = (LN & LN_IN) ? gelu_pk16(a[4 * g + 2] * rs, a[4 * g + 3] * rs) : gelu_pk16(a[4 * g + 2], a[4 * g + 3]);
                             h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
-                            __builtin_amdgcn_sched_barrier(0);   // one run at a time: the GELU temporaries of several would spill
+                            if (g % G2_GELU_RUNS == G2_GELU_RUNS - 1) __builtin_amdgcn_sched_barrier(0);   // the GELU temporaries of more runs at a time would spill
                         } else {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) h[e] = (LN & LN_IN) ? (_Float16)rounded_f32(a[4 * g + e] * rs) : (_Float16)a[4 * g + e];

@@ -123,6 +123,9 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *                          one k-step of the P.V MFMAs, 8 are not (tools/ubench/mfma_shift.hip) — so "the same sentence gives the
  *                          same bits in any batch" holds only with 16.  Cosines against the CPU are unchanged.
  *   BERT_HIP_CHUNK_TOKENS  max tokens evaluated per device pass by the host API (default 262144)
+ *   BERT_HIP_LN_FOLD       1 (default) | 0 — models on the 256 x 256-tile mat-mul route (H = 768): the LayerNorms folded into the mat-muls around
+ *                          them (no LayerNorm launch but the last; roundings differ from the un-folded sequence in the last bits), or a
+ *                          LayerNorm kernel per LayerNorm
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the

@@ -6,7 +6,7 @@ import os
 import subprocess
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r6"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 g = os.path.join(root, "gpurun_out")
 P = os.path.join(root, "profiles")
@@ -57,7 +57,7 @@ c3 = bench["also"]["config3"]
 with open(os.path.join(P, f"{tag}_kernel_stats.txt"), "w") as f:
     f.write(hdr + read(f"stats_{tag}.txt") +
             f"\n# --config 3 (bert-base dims q4_1 expanded to f16 at load, 512 x 512 tokens per step, 12 layers): rocprofv3 --kernel-trace --stats -- python bench.py --config 3 --steps 3 --warmup 1 --repeat 1 --no-cpu-baseline --also\n"
-            f"# gemm256_kernel<EPI, WT>: EPI 0 = QKV (bias), 1 = FFN up (bias + GELU), 2 = attention output and FFN down (bias + residual); WT 0 = f16 image; same box un-profiled: {c3['value']:.0f} sentences/s = {c3['path_mfma_frac']:.3f} of the MFMA peak\n" +
+            f"# gemm256_kernel<EPI, WT, LN>: EPI 0 = QKV (bias), 1 = FFN up (bias + GELU), 2 = attention output and FFN down (bias + residual); WT 0 = f16 image, 2 = q4_1 planes (layer 0's QKV); LN = the LayerNorm fold: 1 the input rows' statistics ride in (QKV of layers >= 1, FFN up), 4 / 6 = 4 the rows' partial sums go out + 2 the residual is rebuilt from the un-normalised rows (attention output, FFN down; 4 alone = layer 0's attention output); same box un-profiled: {c3['value']:.0f} sentences/s = {c3['path_mfma_frac']:.3f} of the MFMA peak\n" +
             read(f"stats_config3_{tag}.txt") +
             (f"\n# --config 33: the same model and batch with BERT_HIP_Q4=fused — the matrices stay 4-bit in HBM, gemm256_kernel<EPI, 2> (q4_1 planes) dequantises the blocks in its tile load; same box un-profiled: "
              f"{bench['also']['config3_fused']['value']:.0f} sentences/s\n" + read(f"stats_config33_{tag}.txt") if os.path.exists(os.path.join(g, f"stats_config33_{tag}.txt")) and "config3_fused" in bench["also"] else ""))

@@ -7,7 +7,7 @@
 # usage (from the repo root on the GPU box):  bash tools/gpu_round_check.sh [tag]      then, here: python tools/assemble_profiles.py [tag]
 set -u
 trap '' PIPE        # (a reader that stops early — `| head` — must not end the run half way)
-TAG=${1:-r5}
+TAG=${1:-r6}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp BERT_HIP_QUIET=1
