@@ -180,6 +180,12 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
     }
     __syncthreads();
     ATT_MARK(0)
+    if constexpr (MULTI) {
+        // vmcnt retires in issue order: a wait for Q fragments BEHIND the requests below waits for the whole next item's rows.  Naming
+        // the fragments here puts the compiler's wait here — they were requested before the staging and have landed.
+#pragma unroll
+        for (int kk = 0; kk < D / 16; ++kk) asm volatile("" : "+v"(qf[kk]));
+    }
     if (PERSIST && v + (int)gridDim.x < n_items) {
         nxt = item_of(v + (int)gridDim.x);
         if (nxt.n > 0) request(nxt, tid);              // in flight under this item's mat-muls
@@ -187,10 +193,12 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
 
     const float sc = 1.44269504088896340736f / __builtin_sqrtf((float)D);   // log2(e) / sqrt(d)
     // One pass = one query block of this wave.  The next query block's Q fragments are requested into the SAME registers behind the
-    // last chunk's S^T MFMAs of the pass before (they are dead there): the round trip runs under that chunk's softmax and P·V.
-    // (Requested a whole pass ahead into registers of their own — and the next item's K / V rows only in the last pass, the pass
-    // body instantiated twice so that the two prefetches never hold registers together — the 8-wave form still spilled 43
-    // registers and ran 11.4 against 8.4 ms per 12 launches at 512 tokens; the 4-wave form of short sentences lost its third wave.)
+    // chunk loop of the pass before (they are dead there) and named at the END of that pass: the round trip runs under the pass's
+    // normalise-and-store, and NO load sits inside the chunk loop.  (Until round 6 they were requested behind the last chunk's S^T
+    // MFMAs, a chunk earlier: the compiler's wait for them then sits at the top of EVERY chunk, and in the first chunk of an item
+    // it also waits for the next item's K / V rows requested just before — vmcnt retires in issue order: 10 k of an item's 62 k
+    // cycles in the phase clock, profiles/r6_experiments.txt §4.  Requested a whole pass ahead into registers of their own the
+    // 8-wave form spilled 43 registers: 11.4 against 8.4 ms per 12 launches at 512 tokens.)
     for (int qb = wave; qb < n_qblocks; qb += NT / 64) {
         f32x16 o[D / 32];
         if constexpr (MULTI) {                         // (the short form's single chunk starts its P·V MFMAs from the constant 0)
@@ -237,12 +245,6 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             }
 #pragma unroll
             for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
-            if (MULTI && kc + CH >= n_steps && qb + NT / 64 < n_qblocks) {
-                const int qrow = min((qb + NT / 64) * 32 + l31, n - 1);
-                const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
-#pragma unroll
-                for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
-            }
             ATT_TL(asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); ATT_MARK(1) asm volatile("" : "+v"(s[0]), "+v"(s[1]), "+v"(s[2]), "+v"(s[3])); ++tl_chunks;)
             // ---- mask the ragged tail (only the sentence's last chunk can have one), chunk max
             if (kc + CH > n) {
@@ -333,19 +335,36 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             ATT_TL(asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1])); ATT_MARK(3) asm volatile("" : "+v"(o[0]), "+v"(o[D / 32 - 1]));)
         }
         // ---- normalise and store: lane (q, hi) owns dv = dvt*32 + 8g + 4hi + 0..3
-        const int q = qb * 32 + l31;
-        if (q < n) {
-            const float inv = 1.0f / l_run;
-            half_t *op = out + (size_t)(tok0 + q) * H + h * D;
+        auto normalise_and_store = [&]() __attribute__((always_inline)) {
+            const int q = qb * 32 + l31;
+            if (q < n) {
+                const float inv = 1.0f / l_run;
+                half_t *op = out + (size_t)(tok0 + q) * H + h * D;
 #pragma unroll
-            for (int dv = 0; dv < D / 32; ++dv)
+                for (int dv = 0; dv < D / 32; ++dv)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 ov;
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 ov;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[e] = (_Float16)rounded_f32(o[dv][4 * g + e] * inv);
-                    *(f16x4 *)(op + dv * 32 + 8 * g + 4 * hi) = ov;
-                }
+                        for (int e = 0; e < 4; ++e) ov[e] = (_Float16)rounded_f32(o[dv][4 * g + e] * inv);
+                        *(f16x4 *)(op + dv * 32 + 8 * g + 4 * hi) = ov;
+                    }
+            }
+        };
+        if (MULTI && qb + NT / 64 < n_qblocks) {
+            // the next pass's fragments: requested in FRONT of this pass's stores, named BEHIND them (the compiler's wait goes where
+            // they are named: at the top of the pass it would, in an item's first pass, wait for the next item's rows), request
+            // and naming in ONE branch (in two, the compiler sees a path on which the request is never waited for and keeps a wait
+            // at the top of every chunk)
+            const int qrow = min((qb + NT / 64) * 32 + l31, n - 1);
+            const half_t *qp = qkv + (size_t)(tok0 + qrow) * ld + h * D + hi * 8;
+#pragma unroll
+            for (int kk = 0; kk < D / 16; ++kk) qf[kk] = *(const f16x8 *)(qp + kk * 16);
+            normalise_and_store();
+#pragma unroll
+            for (int kk = 0; kk < D / 16; ++kk) asm volatile("" : "+v"(qf[kk]));
+        } else {
+            normalise_and_store();
         }
         ATT_MARK(4)
     }
