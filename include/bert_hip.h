@@ -107,7 +107,8 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_KERNELS       "fused" (default): two launches per layer where the shape allows it — projection + attention of a
  *                          128-slot window (qkv_attention2.hip), everything behind the attention (layer_tail.hip) —, tiled kernels
  *                          elsewhere | "tiled": GEMM, attention and LayerNorm kernels only (Q|K|V and the intermediate through
- *                          HBM) | "naive": the generic kernels (any shape; builds row-major f16 images at load)
+ *                          HBM).  ("naive" — the generic kernels the parity tests compare against — is a route of libbert_test.so only;
+ *                          libbert.so prints a note and ignores it.)
  *   BERT_HIP_Q4            "expand" (default) | "fused" — q4_0 / q4_1 weight matrices are expanded to f16 images in HBM once
  *                          at load, or stay 4-bit in HBM and are dequantised in the tile loads of the same kernels (same values,
  *                          same bits on the fused kernels; a quarter of the weight bytes)
@@ -129,7 +130,7 @@ BERT_API int32_t bert_hip_profile_report(struct bert_ctx *ctx, char *buf, int32_
  *   BERT_HIP_QUIET         1 = no progress text on stdout during load, no "unknown token" lines on stderr from bert_tokenize
  * bert_hip_set_option (after load; tests and tuning): "qkv2" / "tail" / "gemm256" / "latency" = "0" | "1" switch single kernels
  * of the fused family, "one_launch" = "0" | "1" (default: all layers in one launch for well-filled windows) | "2" (whenever the
- * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive", "f32" = "exact" | "f16", "latency_tokens" = n, "window_slots" = "16" | "8" (process-wide default, read once
+ * kernel takes the batch), "gemm" / "attn" = "mfma" | "naive" (libbert_test.so), "ln_fold" = "0" | "1", "f32" = "exact" | "f16", "latency_tokens" = n, "window_slots" = "16" | "8" (process-wide default, read once
  * per forward pass), "chunk_tokens" = n, "gather_super_tokens" = n (bert_hip_eval_packed_gather: tokens per device and super-batch, 0 =
  * four device chunks), "stage_kernel" = "0" | "1" (host API: staged blocks of at most 256 KiB travel by a kernel that reads the mapped
  * pinned memory instead of the copy engine), "profile_replay" (above).                                                                 */
