@@ -46,6 +46,12 @@ __device__ __forceinline__ long long att_clock() {
 #else
 #define ATT_TL(...)
 #endif
+#ifndef ATT_S_AHEAD
+#define ATT_S_AHEAD 1                 // long-sentence form: K fragments of S^T requested this many MFMAs ahead (0: the compiler's order)
+#endif
+#ifndef ATT_S_AHEAD_SHORT
+#define ATT_S_AHEAD_SHORT 0           // the same for the short form (sentences up to 128 tokens)
+#endif
 constexpr int ATT_CHUNK = 128;      // keys per online-softmax step (4 S^T tiles of 32)
 constexpr int VT_PAD = 4;           // halfs of padding per V^T row: 8-byte skew -> conflict-free ds_read_b64
 
@@ -234,6 +240,26 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             // register sets, the order pinned by sched_barrier.  In isolation that is the better form — 39 against 66 cycles per MFMA with
             // one wave on the SIMD, 56 against 68 per wave with two, tools/ubench/mfma_chain.hip — in this kernel it is 7 % slower:
             // 9.04 against 8.42-8.47 ms per 12 launches at 512 tokens on one box, level at 128 tokens.)
+            constexpr int S_AHEAD = MULTI ? ATT_S_AHEAD : ATT_S_AHEAD_SHORT;
+            if constexpr (S_AHEAD > 0) {
+                // K fragments requested S_AHEAD MFMAs ahead, the order pinned (one read, one MFMA, alternating): left alone the compiler
+                // puts every fragment into ONE register set — read, wait out the LDS round trip, MFMA, sixteen times per chunk
+                constexpr int NF = KT * (D / 16);
+                f16x8 kfr[NF];
+                auto rd = [&](int f) __attribute__((always_inline)) { kfr[f] = *(const __attribute__((address_space(3))) f16x8 *)(kbase[f % (D / 16)] + (f / (D / 16)) * 32 * K_ROW); };
+#pragma unroll
+                for (int f = 0; f < S_AHEAD; ++f) rd(f);
+                __builtin_amdgcn_sched_group_barrier(0x100, S_AHEAD, 0);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    if (f + S_AHEAD < NF) rd(f + S_AHEAD);
+                    const int kt = f / (D / 16), kk = f % (D / 16);
+                    // (the first k-step starts from the constant 0: no zeroing moves)
+                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfr[f], qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
+                    if (f + S_AHEAD < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+            } else {
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt) {
 #pragma unroll
@@ -242,6 +268,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     // (the first k-step starts from the constant 0: no zeroing moves)
                     s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], kk == 0 ? (f32x16)0.f : s[kt], 0, 0, 0);
                 }
+            }
             }
 #pragma unroll
             for (int kk = 0; kk < D / 16; ++kk) kbase[kk] += CH * K_ROW;
