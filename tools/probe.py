@@ -2,6 +2,7 @@
 """Quick A/B probes for kernel work, one gpurun call for several libraries (BERT_HIP_LIB=bert.cpp_amd/libbert_<variant>.so, built by
 tools/variant.sh):
     probe.py rate [regions]          device-resident sentences/s of configs[1]'s shape (256 x 128, f16), 300-step regions
+                                     (PROBE_OPTIONS=key=value,...: bert_hip_set_option calls after the load)
     probe.py kernels <config> [...]  per-kernel HIP-event milliseconds per step of one bench config (bench.py's CONFIGS ids)
     probe.py latency [n_tokens] [calls]   one sentence per call through bert_hip_eval_packed: median microseconds, host to host
 """
@@ -27,6 +28,8 @@ def rate(regions=3):
         p = os.path.join(d, "m.bin")
         hp = gf.make_synthetic_model(p, "minilm-l6", "f16", seed=0)
         m = pybert.BertModel(p)
+        for kv in filter(None, os.environ.get("PROBE_OPTIONS", "").split(",")):      # e.g. PROBE_OPTIONS=one_launch=0
+            m.set_option(*kv.split("="))
         B = 256
         ids = gf.synthetic_token_ids(B, 128, hp.n_vocab, seed=1235)
         t = torch.from_numpy(ids.reshape(-1).copy()).to(dev)
