@@ -989,6 +989,38 @@ def test_workspace_growth_does_not_race_with_the_forward_pass(make_model):
         m.close()
 
 
+@pytest.mark.parametrize("ftype", ["f16", "q4_1"])
+def test_bert_large_dims_both_layernorm_routes(make_model, ftype, monkeypatch):
+    """H = 1024 (bert-large's width: sixteen heads of 64, I = 4096, two layers here): wider than anything BASELINE.json names — eight
+    statistics partials per row in the folded LayerNorms, four feature tiles in the residual mat-muls.  Mixed lengths up to 300
+    tokens (the long-sentence attention form), enough tokens for the 256 x 256-tile mat-muls: the folded route and the plain one
+    agree with each other to rounding noise and with the oracle in both of its modes."""
+    gf.MODEL_DIMS.setdefault("h1024-l2", gf.BertHParams(2000, 512, 1024, 4096, 16, 2))
+    path, hp = make_model("h1024-l2", ftype, 0)
+    rng = np.random.default_rng(11)
+    lens = np.concatenate([rng.integers(3, 301, size=30), [300, 1, 128, 129]])
+    sents = [rng.integers(0, hp.n_vocab, size=int(n)).astype(np.int32) for n in lens]
+    outs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("BERT_HIP_LN_FOLD", fold)
+        m = pybert.BertModel(path)
+        m.profile(True)
+        outs[fold] = m.eval_batch(sents)
+        rep = m.profile_report(families=True)
+        m.profile(False)
+        assert ("ln_rows_finalize" in rep) == (fold == "1"), sorted(rep)
+        assert rep["layernorm"]["launches"] == (1 if fold == "1" else 2 * hp.n_layer), rep["layernorm"]
+        assert not any(k.startswith("family:gemm_mfma") or k.startswith("family:gemm_naive") for k in rep), sorted(rep)
+        m.close()
+    assert np.isfinite(outs["1"]).all() and np.abs(np.linalg.norm(outs["1"], axis=1) - 1).max() < 1e-3
+    assert min(cosine(a, b) for a, b in zip(outs["1"], outs["0"])) > 1 - 2e-6
+    o = orc.Oracle(path)
+    for i in (0, 7, 30, 31, 33):
+        assert cosine(outs["1"][i], o.eval(sents[i], orc.MODE_GGML)) >= TIGHT_COS_GGML[ftype], i
+        assert cosine(outs["0"][i], o.eval(sents[i], orc.MODE_GGML)) >= TIGHT_COS_GGML[ftype], i
+    assert cosine(outs["1"][33], o.eval(sents[33], orc.MODE_PLAIN)) >= (TIGHT_COS_PLAIN if ftype == "f16" else 0.999)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE sizes through size-independent properties
 # ------------------------------------------------------------------------------------------------
