@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) mx = __builtin_fmaxf(__builtin_fmaxf(s[kt][r], s[kt][r + 1]), mx);   // v_max3_f32
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = xor32_max(mx);
             // the scale is positive: max(s) * sc is the maximum of the scaled scores, bit for bit
             const float m_new = fmaxf(m_run, mx * sc);      // finite: every step has >= 1 real key
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);        // 0 on the first chunk
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                     for (int st = 0; st < 2; ++st)
                         pfr[kt][st] = softmax_p8(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
                                                  s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new, psum);
-                psum += __shfl_xor(psum, 32);
+                psum = xor32_sum(psum);
                 l_run = l_run * alpha + psum;
                 m_run = m_new;
                 __builtin_amdgcn_sched_barrier(0);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(NT) void attention_mfma_kernel(const half_t *__rest
                 for (int st = 0; st < 2; ++st)
                     pfr[kt][st] = softmax_p8(s[kt][8 * st], s[kt][8 * st + 1], s[kt][8 * st + 2], s[kt][8 * st + 3], s[kt][8 * st + 4],
                                              s[kt][8 * st + 5], s[kt][8 * st + 6], s[kt][8 * st + 7], sc, m_new, psum);
-            psum += __shfl_xor(psum, 32);
+            psum = xor32_sum(psum);
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll

@@ -443,8 +443,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(Gemm256Args p) {
             // the two lane halves hold the two 4-feature runs of every 8: one partial per (row, 128-feature half of the tile)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                st1[j] += __shfl_xor(st1[j], 32);
-                st2[j] += __shfl_xor(st2[j], 32);
+                st1[j] = xor32_sum(st1[j]);
+                st2[j] = xor32_sum(st2[j]);
             }
             if (hi == 0) {
 #pragma unroll

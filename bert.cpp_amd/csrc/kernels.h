@@ -23,6 +23,30 @@ __device__ __forceinline__ float rounded_f32(float v) {
     return v;
 }
 
+// ---- lane-crossing reductions without the LDS.  __shfl_xor is a ds_bpermute_b32: an LDS round trip (and an lgkmcnt wait) per step.
+// The same PAIRS meet here — so sums and maxima keep their bits — through v_permlane32_swap (lane ^ 32: the two halves of the wave
+// trade places), ds_swizzle (lane ^ 16 / 8 / 4: no address register, no LDS access) and DPP quad_perm on the add itself (lane ^ 2 / 1).
+// tools/ubench/wave_sum.hip checks the six-step sum against the __shfl_xor butterfly bit for bit.
+// xor32_pair: a = this lane's value, b = lane ^ 32's in the low half of the wave and the other way round in the high half — fine for
+// commutative uses (a + b, max(a, b)).  By hand: this compiler's __builtin_amdgcn_permlane32_swap returns its first result twice; the
+// instruction needs two registers (with one as both operands it copies the low half up and loses the high one); the wait states
+// between a VALU write and a lane-crossing read are ours inside an asm.
+__device__ __forceinline__ void xor32_pair(float &a, float &b) {
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float xor32_sum(float v) { float a = v, b = v; xor32_pair(a, b); return a + b; }
+__device__ __forceinline__ float xor32_max(float v) { float a = v, b = v; xor32_pair(a, b); return __builtin_fmaxf(a, b); }
+// v + (lane ^ 32) + ... + (lane ^ 1), the pairs and the order of the __shfl_xor butterfly from 32 down to 1
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v = xor32_sum(v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1F));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (8 << 10) | 0x1F));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (4 << 10) | 0x1F));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    return v;
+}
+
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 

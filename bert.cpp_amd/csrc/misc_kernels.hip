@@ -10,11 +10,7 @@ namespace bert_hip {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_f32(v); }      // (kernels.h: the __shfl_xor butterfly's pairs without the LDS)
 
 // Element e of row r of an embedding table stored in the model-file layout,
 // dequantised to f32 exactly as ggml_get_rows does: f16 -> f32, (q-8)*d, q*d+m.

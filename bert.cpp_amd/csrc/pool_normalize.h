@@ -10,11 +10,7 @@ namespace bert_hip {
 typedef _Float16 pool_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pool_f16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float pool_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ float pool_wave_sum(float v) { return wave_sum_f32(v); }
 
 // Sentence b = rows tok0 .. tok0 + n - 1 of x.  Wave w (of four) sums tokens w, w+4, ... over 16-byte (H % 8 == 0) or 4-byte row
 // reads, the four partial rows are combined through LDS: part = [4][H] floats + 4.  Every thread of the workgroup calls this

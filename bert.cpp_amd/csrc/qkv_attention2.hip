@@ -472,7 +472,7 @@ __device__ __forceinline__ void qkv_attention2_body(const Qkv2Args &a, char *sme
                     }
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc;          // = the maximum of the scaled scores, as attention.hip
+            mx = xor32_max(mx) * sc;          // = the maximum of the scaled scores, as attention.hip
             mx = fmaxf(mx, -3.0e38f);                         // empty slots (no keys): keeps exp2(-inf - mx) = 0, no NaN
             // ---- softmax (one fma + exp2 per score), O^T = V^T P^T
             float psum = 0.f;
@@ -505,7 +505,7 @@ __device__ __forceinline__ void qkv_attention2_body(const Qkv2Args &a, char *sme
                 }
             }
             // ---- normalise, store
-            psum += __shfl_xor(psum, 32);
+            psum = xor32_sum(psum);
             if (gtok >= 0) {
                 const float inv = 1.0f / psum;
                 half_t *op = a.out + (size_t)gtok * H + hh * 32;
